@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- compress+decompress GB/s (uncompressed side) of the blosc2 chunk codec path on MI355X.
+
+Workload (BASELINE.json configs[1]): 4 channels of 4096x4096 float16, lz4 level 9 + byte shuffle,
+32 KiB blocks, 4 MiB chunks (8 chunks per channel, 128 blocks per chunk, 2 x 16 KiB streams per
+block), seeded synthetic "tiled channel" data (cimg/synth.py).  One *step* =
+compress all 32 chunks (one batched call) + decompress them (one batched call), pixels and chunks
+resident in HBM.  value = ranks * steps * 2 * N / wall  (N = 128 MiB per rank; weak scaling: every rank
+owns its own 4 channels, there is no data-path collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the kernel with the largest share of device time
+(HIP events recorded on the engine's stream around every launch); `kernels` lists all four.
+`cpu_baseline` times the oracle (CPU restatement, oracle/) on the host cores -- it is the checker
+being timed, never part of the measured GPU path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "compressed-image_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: keeps one HIP runtime in the process)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak is ~6300
+
+WIDTH = HEIGHT = 4096
+CHANNELS = 4
+DTYPE = np.float16
+CHUNK = 4 * 1024 * 1024
+BLOCK = 32768
+
+
+def cpu_baseline(raw_channels, budget_s=12.0):
+    """Oracle compress+decompress of the same chunks on the host cores (bounded sample)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import _oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    O.lib()
+    p = O.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK)
+    raw = raw_channels[0].view(np.uint8).ravel()           # one channel = 8 chunks = 32 MiB
+    pieces = [raw[o:o + CHUNK] for o in range(0, raw.size, CHUNK)]
+
+    def one(piece):
+        r, c = O.compress(p, piece, destsize=CHUNK + 32)
+        rr, out = O.decompress(c, piece.size)
+        return r, rr
+
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(one, pieces))                           # warm
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            list(ex.map(one, pieces))
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= 200:
+                break
+        dt = time.perf_counter() - t0
+    gbps = reps * 2 * raw.size / dt / 1e9
+    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (oracle/ CPU restatement, not c-blosc2): channel 0 = {len(pieces)} chunks x 4 MiB, "
+                      f"compress+decompress, {reps} passes over a {cores}-thread pool, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--family", default="tiled", choices=["tiled", "natural", "random", "zero"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (MI355X); none visible", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from cimg import hip, synth
+
+    # ---- inputs: this rank's 4 channels, resident in HBM ------------------------------------------------
+    gen = getattr(synth, args.family + "_channel")
+    chans = []
+    for c in range(CHANNELS):
+        if args.family == "zero":
+            chans.append(gen(DTYPE, WIDTH, HEIGHT))
+        else:
+            chans.append(gen(DTYPE, WIDTH, HEIGHT, c=CHANNELS * rank + c))
+    host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    N = host.size
+    nchunks = N // CHUNK
+    stride = CHUNK + 64
+    d_raw = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    d_comp = torch.zeros(nchunks * stride, dtype=torch.uint8, device="cuda")
+    raw_off = np.arange(nchunks, dtype=np.int64) * CHUNK
+    comp_off = np.arange(nchunks, dtype=np.int64) * stride
+    nbytes = np.full(nchunks, CHUNK, np.int32)
+    destsize = np.full(nchunks, CHUNK + 32, np.int32)          # schunk.h:73: nominal chunk + BLOSC2_MAX_OVERHEAD
+    blocksize = np.full(nchunks, BLOCK, np.int32)
+    torch.cuda.synchronize()
+
+    eng = hip.Engine(local_rank)
+    p = hip.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4)
+
+    def step():
+        cb = eng.compress_device(p, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
+        eng.decompress_device(d_comp.data_ptr(), comp_off, nbytes, blocksize, d_out.data_ptr(), raw_off)
+        return cb
+
+    cbytes = step()
+    if not torch.equal(d_out, d_raw):
+        print("bench.py: decompressed pixels differ from the input -- refusing to report a number", file=sys.stderr)
+        sys.exit(3)
+    for _ in range(args.warmup):
+        step()
+
+    eng.enable_timing(True)
+    eng.reset_timing()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        csum = torch.tensor([float(cbytes.sum())], dtype=torch.float64, device="cuda")
+        dist.all_reduce(csum, op=dist.ReduceOp.SUM)
+        total_c = float(csum.item())
+    else:
+        total_c = float(cbytes.sum())
+
+    ktimes = [eng.kernel_time(k) for k in range(4)]
+    eng.enable_timing(False)
+    if not torch.equal(d_out, d_raw):
+        print("bench.py: pixels differ after the timed region", file=sys.stderr)
+        sys.exit(3)
+
+    if rank == 0:
+        C = float(cbytes.sum())
+        algo = {hip.K_ENCODE: N + C, hip.K_LAYOUT: 0.0, hip.K_EMIT: 0.0, hip.K_DECODE: C + N}
+        kernels = {}
+        for k, (ms, n) in enumerate(ktimes):
+            avg = ms / n if n else 0.0
+            kernels[hip.KERNELS[k]] = {
+                "launches": n, "avg_us": round(avg * 1e3, 2),
+                "algorithmic_GBps": round(algo[k] / (avg * 1e-3) / 1e9, 1) if avg > 0 and algo[k] else None}
+        dom = max(range(4), key=lambda k: ktimes[k][0])
+        dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
+        achieved = algo[dom] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
+        dec_avg_s = ktimes[hip.K_DECODE][0] / max(ktimes[hip.K_DECODE][1], 1) * 1e-3
+        out = {
+            "metric": "compress+decompress GB/s (uncompressed side)",
+            "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3),
+            "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{CHANNELS}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + byte shuffle, "
+                                   f"32 KiB blocks, 4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks, {2 * N // BLOCK} streams), "
+                                   f"device-resident, family={args.family}",
+                       "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(C),
+                       "compression_ratio": round(world * N / total_c, 4) if total_c else None,
+                       "roundtrip_GBps": round(world * args.steps * N / elapsed / 1e9, 3),
+                       "parallelism": f"chunks sharded by rank x{world}, no data-path collective"},
+            "roofline": {"kernel": hip.KERNELS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_us": round(dom_avg_s * 1e6, 2)},
+            "roofline_decode": {"kernel": hip.KERNELS[hip.K_DECODE], "bound": "hbm",
+                                "achieved": round((C + N) / dec_avg_s / 1e9, 1) if dec_avg_s > 0 else None,
+                                "output_side": round(N / dec_avg_s / 1e9, 1) if dec_avg_s > 0 else None,
+                                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": round((C + N) / dec_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if dec_avg_s > 0 else None},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(chans)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,262 @@
+"""ctypes binding of libcimg_hip.so (include/cimg_hip.h + include/blosc2.h).
+
+Plumbing for bench.py, __graft_entry__.py and the GPU tests: it only marshals pointers and sizes
+into the C ABI.  There is no fallback: if the library is missing or no gfx950 device is present the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libcimg_hip.so")
+
+K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE = 0, 1, 2, 3
+KERNELS = ("cimg_encode_blocks", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")
+BLOSCLZ, LZ4, LZ4HC, ZLIB, ZSTD = 0, 1, 2, 4, 5
+NOFILTER, SHUFFLE, BITSHUFFLE = 0, 1, 2
+MAX_OVERHEAD = 32
+
+EXPORTS = (
+    # include/cimg_hip.h
+    "cimg_cparams_init", "cimg_engine_create", "cimg_engine_destroy", "cimg_last_error",
+    "cimg_engine_synchronize", "cimg_engine_stream", "cimg_compress_batch_device",
+    "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host",
+    "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h",
+    "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
+    # include/blosc2.h
+    "blosc2_create_cctx", "blosc2_create_dctx", "blosc2_free_ctx", "blosc2_compress_ctx",
+    "blosc2_decompress_ctx", "blosc2_cbuffer_sizes", "blosc2_schunk_new", "blosc2_schunk_free",
+    "blosc2_schunk_append_chunk", "register_filters", "print_error",
+)
+
+
+class CodecError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"blosc2 error {code}: {msg}")
+        self.code = code
+
+
+class CParams(C.Structure):
+    _fields_ = [("typesize", C.c_int32), ("clevel", C.c_int32), ("blocksize", C.c_int32),
+                ("compcode", C.c_int32), ("splitmode", C.c_int32),
+                ("filters", C.c_uint8 * 6), ("filters_meta", C.c_uint8 * 6)]
+
+
+class Blosc2CParams(C.Structure):
+    _fields_ = [("compcode", C.c_uint8), ("compcode_meta", C.c_uint8), ("clevel", C.c_uint8),
+                ("use_dict", C.c_int), ("typesize", C.c_int32), ("nthreads", C.c_int16),
+                ("blocksize", C.c_int32), ("splitmode", C.c_int32), ("schunk", C.c_void_p),
+                ("filters", C.c_uint8 * 6), ("filters_meta", C.c_uint8 * 6),
+                ("prefilter", C.c_void_p), ("preparams", C.c_void_p), ("tuner_params", C.c_void_p),
+                ("tuner_id", C.c_int), ("instr_codec", C.c_bool), ("codec_params", C.c_void_p),
+                ("filter_params", C.c_void_p * 6)]
+
+
+class Blosc2DParams(C.Structure):
+    _fields_ = [("nthreads", C.c_int16), ("schunk", C.c_void_p), ("postfilter", C.c_void_p),
+                ("postparams", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (raises OSError if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"(or `make -C compressed-image_amd`)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.cimg_cparams_init.argtypes = [C.POINTER(CParams), C.c_int32]
+    L.cimg_engine_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.cimg_engine_destroy.argtypes = [vp]
+    L.cimg_last_error.argtypes = [vp]
+    L.cimg_last_error.restype = C.c_char_p
+    L.cimg_engine_synchronize.argtypes = [vp]
+    L.cimg_engine_stream.argtypes = [vp]
+    L.cimg_engine_stream.restype = vp
+    L.cimg_compress_batch_device.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_decompress_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_compress_batch_host.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_decompress_batch_host.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.cimg_device_malloc.argtypes = [vp, C.c_size_t]
+    L.cimg_device_malloc.restype = vp
+    L.cimg_device_free.argtypes = [vp, vp]
+    L.cimg_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.cimg_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.cimg_engine_enable_timing.argtypes = [vp, C.c_int]
+    L.cimg_engine_reset_timing.argtypes = [vp]
+    L.cimg_engine_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.cimg_kernel_name.argtypes = [C.c_int]
+    L.cimg_kernel_name.restype = C.c_char_p
+    L.blosc2_create_cctx.argtypes = [Blosc2CParams]
+    L.blosc2_create_cctx.restype = vp
+    L.blosc2_create_dctx.argtypes = [Blosc2DParams]
+    L.blosc2_create_dctx.restype = vp
+    L.blosc2_free_ctx.argtypes = [vp]
+    L.blosc2_compress_ctx.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+    L.blosc2_decompress_ctx.argtypes = [vp, vp, C.c_int32, vp, C.c_int32]
+    L.blosc2_cbuffer_sizes.argtypes = [vp, i32p, i32p, i32p]
+    L.print_error.argtypes = [C.c_int]
+    L.print_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def cparams(typesize, clevel=9, blocksize=32768, compcode=LZ4, splitmode=3, filters=(0, 0, 0, 0, 0, SHUFFLE)):
+    p = CParams()
+    load().cimg_cparams_init(C.byref(p), typesize)
+    p.clevel, p.blocksize, p.compcode, p.splitmode = clevel, blocksize, compcode, splitmode
+    for i, f in enumerate(filters):
+        p.filters[i] = f
+    return p
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i64(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int64))
+
+
+def _i32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+
+
+class DeviceBuffer:
+    """A device allocation owned through the C ABI (no HIP / torch types involved)."""
+
+    def __init__(self, engine, nbytes):
+        self.engine, self.nbytes = engine, int(nbytes)
+        self.ptr = load().cimg_device_malloc(engine.handle, self.nbytes)
+        if not self.ptr:
+            raise CodecError(-4, engine.last_error())
+
+    def upload(self, host, offset=0):
+        h = np.ascontiguousarray(host).view(np.uint8).ravel()
+        self.engine._check(load().cimg_memcpy_h2d(self.engine.handle, self.ptr + offset, _ptr(h), h.size))
+
+    def download(self, nbytes=None, offset=0):
+        n = self.nbytes - offset if nbytes is None else int(nbytes)
+        out = np.empty(n, np.uint8)
+        self.engine._check(load().cimg_memcpy_d2h(self.engine.handle, _ptr(out), self.ptr + offset, n))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().cimg_device_free(self.engine.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One MI355X codec engine (stream + scratch) -- wraps cimg_engine_*."""
+
+    def __init__(self, device=-1):
+        self.handle = C.c_void_p()
+        rc = load().cimg_engine_create(device, C.byref(self.handle))
+        if rc != 0:
+            raise CodecError(rc, load().cimg_last_error(None).decode())
+
+    def close(self):
+        if self.handle:
+            load().cimg_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return load().cimg_last_error(self.handle).decode()
+
+    def _check(self, rc):
+        if rc < 0:
+            raise CodecError(rc, self.last_error())
+        return rc
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def synchronize(self):
+        self._check(load().cimg_engine_synchronize(self.handle))
+
+    # ---- device-resident batches (pointers are raw device addresses: DeviceBuffer.ptr or tensor.data_ptr()) ----
+    def compress_device(self, p, d_raw, raw_off, nbytes, d_comp, comp_off, destsize):
+        raw_off, comp_off, nbytes, destsize = _i64(raw_off), _i64(comp_off), _i32(nbytes), _i32(destsize)
+        cbytes = np.zeros(nbytes.size, np.int32)
+        self._check(load().cimg_compress_batch_device(self.handle, C.byref(p), nbytes.size, d_raw, _ptr(raw_off), _ptr(nbytes),
+                                                      d_comp, _ptr(comp_off), _ptr(destsize), _ptr(cbytes)))
+        return cbytes
+
+    def decompress_device(self, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, check=True):
+        raw_off, comp_off, nbytes, blocksize = _i64(raw_off), _i64(comp_off), _i32(nbytes), _i32(blocksize)
+        status = np.zeros(nbytes.size, np.int32)
+        rc = load().cimg_decompress_batch_device(self.handle, nbytes.size, d_comp, _ptr(comp_off), _ptr(nbytes), _ptr(blocksize),
+                                                 d_raw, _ptr(raw_off), _ptr(status))
+        if check:
+            self._check(rc)
+        return status
+
+    # ---- host-resident batches ----
+    def compress_host(self, p, raw, nbytes, destsize):
+        """raw: numpy array holding the chunks back to back.  Returns list of chunk bytes (b'' = does not fit)."""
+        raw = np.ascontiguousarray(raw).view(np.uint8).ravel()
+        nbytes, destsize = _i32(nbytes), _i32(destsize)
+        raw_off = _i64(np.concatenate([[0], np.cumsum(nbytes[:-1], dtype=np.int64)]))
+        stride = int(destsize.max()) + 32
+        comp_off = _i64(np.arange(nbytes.size, dtype=np.int64) * stride)
+        comp = np.zeros(stride * nbytes.size, np.uint8)
+        cbytes = np.zeros(nbytes.size, np.int32)
+        self._check(load().cimg_compress_batch_host(self.handle, C.byref(p), nbytes.size, _ptr(raw), _ptr(raw_off), _ptr(nbytes),
+                                                    _ptr(comp), _ptr(comp_off), _ptr(destsize), _ptr(cbytes)))
+        return [comp[o:o + max(c, 0)].tobytes() for o, c in zip(comp_off, cbytes)]
+
+    def decompress_host(self, chunks, check=True):
+        """chunks: list of bytes.  Returns (list of uint8 arrays, status array)."""
+        sizes = [len(c) for c in chunks]
+        comp_off = _i64(np.concatenate([[0], np.cumsum(sizes[:-1], dtype=np.int64)]))
+        comp = np.frombuffer(b"".join(chunks), np.uint8)
+        nb = _i32([int.from_bytes(c[4:8], "little", signed=True) for c in chunks])
+        raw_off = _i64(np.concatenate([[0], np.cumsum(nb[:-1], dtype=np.int64)]))
+        raw = np.zeros(max(int(nb.sum()), 1), np.uint8)
+        status = np.zeros(nb.size, np.int32)
+        rc = load().cimg_decompress_batch_host(self.handle, nb.size, _ptr(comp), _ptr(comp_off), _ptr(raw), _ptr(raw_off),
+                                               _ptr(nb), _ptr(status))
+        if check:
+            self._check(rc)
+        return [raw[o:o + n] for o, n in zip(raw_off, nb)], status
+
+    # ---- timing ----
+    def enable_timing(self, on=True):
+        load().cimg_engine_enable_timing(self.handle, 1 if on else 0)
+
+    def reset_timing(self):
+        load().cimg_engine_reset_timing(self.handle)
+
+    def kernel_time(self, kernel):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._check(load().cimg_engine_kernel_time(self.handle, kernel, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def cbuffer_sizes(chunk):
+    c = np.frombuffer(bytes(chunk[:32]), np.uint8)
+    a, b, d = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = load().blosc2_cbuffer_sizes(_ptr(c), C.byref(a), C.byref(b), C.byref(d))
+    if rc < 0:
+        raise CodecError(rc, load().print_error(rc).decode())
+    return a.value, b.value, d.value

@@ -1,0 +1,180 @@
+// assemble_kernel.h -- turn per-stream records + scratch payloads into finished blosc2 chunks.
+//
+//   layout_chunks  one wave per chunk.  Wave-wide prefix sum over the chunk's stream records gives
+//                  every block its bstart and the chunk its cbytes, and re-applies blosc2's
+//                  running-destsize rule (the reference always passes the
+//                  NOMINAL chunk size + 32 as destsize, schunk.h:73): a stream that would not fit
+//                  turns the whole chunk into a memcpyed chunk; a chunk whose streams are all zero
+//                  runs becomes the 32-byte special-zero chunk.  Writes header + bstarts.
+//   emit_blocks    one 256-thread workgroup per block: writes the csize words and copies the
+//                  payloads from the scratch slot to their final place (or the raw pixels for a
+//                  memcpyed chunk).
+// The CPU twin of this split is oracle/chunk.c: orc_blosc2_compress_2phase.
+#pragma once
+#include "codec_types.h"
+#include "wave.h"
+#include "decode_kernel.h"
+
+namespace cimg {
+
+struct AssembleArgs {
+    const ChunkDesc* descs;
+    int32_t nchunks;
+    CodecParams p;
+    const uint8_t* raw;
+    const uint8_t* scratch;
+    const StreamRec* recs;
+    uint8_t* comp;             // chunks are written at comp + desc.comp_off
+    ChunkLayout* layout;       // per chunk
+};
+
+CIMG_DEV int rec_payload(const StreamRec& r) { return r.kind == REC_RUN ? (r.value > 0 ? 1 : 0) : r.csize; }
+
+struct LayoutChunk {
+    const AssembleArgs& a;
+    int chunk;
+    CIMG_DEV LayoutChunk(const AssembleArgs& a_, int chunk_) : a(a_), chunk(chunk_) {}
+
+    CIMG_DEV void write_header(const ChunkDesc& d, uint8_t* c, int flags, int cbytes, int blosc2_flags)
+    {
+        LV<uint32_t> byte;
+        FOR_LANES(l) {
+            uint32_t v = 0;
+            if (l == 0) v = 5;                                        // BLOSC2_VERSION_FORMAT_STABLE
+            else if (l == 1) v = 1;                                   // codec format version
+            else if (l == OFF_FLAGS) v = (uint32_t)flags;
+            else if (l == OFF_TYPESIZE) v = (uint32_t)(a.p.typesize > 255 ? 1 : a.p.typesize);
+            else if (l >= OFF_NBYTES && l < OFF_NBYTES + 4) v = ((uint32_t)d.nbytes >> (8 * (l - OFF_NBYTES))) & 0xFF;
+            else if (l >= OFF_BLOCKSIZE && l < OFF_BLOCKSIZE + 4) v = ((uint32_t)d.blocksize >> (8 * (l - OFF_BLOCKSIZE))) & 0xFF;
+            else if (l >= OFF_CBYTES && l < OFF_CBYTES + 4) v = ((uint32_t)cbytes >> (8 * (l - OFF_CBYTES))) & 0xFF;
+            else if (l == OFF_FILTERS + 5) v = (uint32_t)a.p.filter;
+            else if (l == OFF_COMPCODE) v = (uint32_t)a.p.compcode;
+            else if (l == OFF_BLOSC2_FLAGS) v = (uint32_t)blosc2_flags;
+            byte[l] = v;
+        }
+        FOR_LANES(l) { if (l < HEADER_LEN) c[l] = (uint8_t)byte[l]; }
+    }
+
+    CIMG_DEV void run()
+    {
+        const ChunkDesc& d = a.descs[chunk];
+        uint8_t* c = a.comp + d.comp_off;
+        ChunkLayout lay;
+        lay.cbytes = 0; lay.mode = 3;
+        const int memcpy_bytes = d.nbytes + HEADER_LEN;
+        bool fits = !d.memcpyed;
+        int nt = HEADER_LEN + 4 * d.nblocks;
+        if (fits && nt > d.destsize) fits = false;
+        if (fits) {
+            const int ts = a.p.typesize;
+            const int nfull = d.leftover ? d.nblocks - 1 : d.nblocks;
+            const int per_full = d.split ? ts : 1;
+            const int total = nfull * per_full + (d.leftover ? 1 : 0);
+            for (int i0 = 0; i0 < total && fits; i0 += 64) {
+                LV<int> sz, pre;
+                LV<bool> bad, first;
+                LV<int> blk;
+                FOR_LANES(l) {
+                    const int i = i0 + l;
+                    sz[l] = 0; bad[l] = false; first[l] = false; blk[l] = 0;
+                    if (i < total) {
+                        int jb, s;
+                        if (i < nfull * per_full) { jb = i / per_full; s = i - jb * per_full; } else { jb = nfull; s = 0; }
+                        const StreamRec r = a.recs[(int64_t)(d.blk0 + jb) * a.p.streams_per_block + s];
+                        sz[l] = 4 + rec_payload(r);
+                        first[l] = s == 0;
+                        blk[l] = jb;
+                    }
+                }
+                int tile_total;
+                wave_exscan(sz, pre, tile_total);
+                FOR_LANES(l) {
+                    const int i = i0 + l;
+                    if (i < total) {
+                        int jb, s;
+                        if (i < nfull * per_full) { jb = i / per_full; s = i - jb * per_full; } else { jb = nfull; s = 0; }
+                        const StreamRec r = a.recs[(int64_t)(d.blk0 + jb) * a.p.streams_per_block + s];
+                        const int bsize = (jb == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
+                        const int neblock = bsize / ((d.split && !(jb == d.nblocks - 1 && d.leftover)) ? ts : 1);
+                        const int N = nt + pre[l] + 4;               // offset right after this stream's csize word
+                        bool f = false;
+                        if (r.kind == REC_RUN) {
+                            f = N > d.destsize || (r.value > 0 && N + 1 > d.destsize);
+                        } else {
+                            int maxout = neblock;
+                            if (N + maxout > d.destsize) { maxout = d.destsize - N; if (maxout <= 0) f = true; }
+                            if (!f) {
+                                if (r.kind == REC_LZ4) { if (r.need > maxout) f = true; }
+                                else if (N + neblock > d.destsize) f = true;
+                            }
+                        }
+                        bad[l] = f;
+                        if (first[l]) st32(c + HEADER_LEN + 4 * blk[l], nt + pre[l]);
+                    }
+                }
+                if (ballot(bad)) fits = false;
+                nt += tile_total;
+            }
+            if (fits) {
+                if (nt == HEADER_LEN + 4 * d.nblocks + 4 * total) {
+                    lay.cbytes = HEADER_LEN; lay.mode = 2;
+                    write_header(d, c, d.flags, HEADER_LEN, SPECIAL_ZERO << 4);
+                } else {
+                    lay.cbytes = nt; lay.mode = 0;
+                    write_header(d, c, d.flags, nt, 0);
+                }
+            }
+        }
+        if (!fits) {
+            if (memcpy_bytes <= d.destsize) {
+                lay.cbytes = memcpy_bytes; lay.mode = 1;
+                write_header(d, c, d.flags | FLAG_MEMCPYED, memcpy_bytes, 0);
+            } else {
+                lay.cbytes = 0; lay.mode = 3;
+                if (d.destsize >= HEADER_LEN) write_header(d, c, d.flags, 0, 0);
+            }
+        }
+        FOR_LANES(l) { if (l == 0) a.layout[chunk] = lay; }
+    }
+};
+
+struct EmitBlock {
+    const AssembleArgs& a;
+    int b;
+    CIMG_DEV EmitBlock(const AssembleArgs& a_, int b_) : a(a_), b(b_) {}
+
+    CIMG_DEV void run(int wave)
+    {
+        const int chunk = find_chunk(a.descs, a.nchunks, b);
+        const ChunkDesc& d = a.descs[chunk];
+        const int j = b - d.blk0;
+        uint8_t* c = a.comp + d.comp_off;
+        const int mode = a.layout[chunk].mode;
+        const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
+        const int bsize = leftover_blk ? d.leftover : d.blocksize;
+        if (mode == 1) {
+            wave_copy_g2g(a.raw + d.raw_off + (int64_t)j * d.blocksize, c + HEADER_LEN + (int64_t)j * d.blocksize, bsize, wave, 4);
+            return;
+        }
+        if (mode != 0) return;
+        const int ns = (d.split && !leftover_blk) ? a.p.typesize : 1;
+        const int neblock = bsize / ns;
+        const uint8_t* slot = a.scratch + (int64_t)b * a.p.slot_bytes;
+        int pos = ld32s(c + HEADER_LEN + 4 * j);
+        for (int s = 0; s < ns; s++) {
+            const StreamRec r = a.recs[(int64_t)b * a.p.streams_per_block + s];
+            if (wave == 0) {
+                const int word = r.kind == REC_RUN ? -r.value : r.csize;
+                FOR_LANES(l) {
+                    if (l < 4) c[pos + l] = (uint8_t)(((uint32_t)word >> (8 * l)) & 0xFF);
+                    if (l == 4 && r.kind == REC_RUN && r.value > 0) c[pos + 4] = 0x01;
+                }
+            }
+            pos += 4;
+            if (r.kind != REC_RUN) wave_copy_g2g(slot + (int64_t)s * neblock, c + pos, r.csize, wave, 4);
+            pos += rec_payload(r);
+        }
+    }
+};
+
+}  // namespace cimg

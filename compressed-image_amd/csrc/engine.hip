@@ -1,0 +1,436 @@
+// engine.hip -- libcimg_hip.so: kernel entry points, the batch engine and the C ABI of
+// include/cimg_hip.h.  gfx950 only.  There is no CPU path in this library: every codec call ends in
+// one of the four kernels below or in an error code.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "plan.h"
+#include "assemble_kernel.h"
+#include "../../include/cimg_hip.h"
+
+using namespace cimg;
+
+// ====================================================================================================
+//  kernels
+// ====================================================================================================
+extern "C" __global__ __launch_bounds__(256) void cimg_encode_blocks(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    EncodeBlock blk(a, lds, (int)blockIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    blk.phase_a(wave);
+    __syncthreads();
+    blk.phase_b(wave);
+}
+
+extern "C" __global__ __launch_bounds__(64) void cimg_layout_chunks(AssembleArgs a)
+{
+    LayoutChunk lc(a, (int)blockIdx.x);
+    lc.run();
+}
+
+extern "C" __global__ __launch_bounds__(256) void cimg_emit_blocks(AssembleArgs a)
+{
+    EmitBlock eb(a, (int)blockIdx.x);
+    eb.run(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
+}
+
+extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    DecodeBlock blk(a, lds, (int)blockIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    blk.phase_a(wave);
+    __syncthreads();
+    blk.phase_b(wave);
+}
+
+// ====================================================================================================
+//  engine
+// ====================================================================================================
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct cimg_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf descs, recs, layout, scratch, status, stage_raw, stage_comp;
+    PinBuf h_descs, h_out;
+    int max_dyn_lds[2] = {0, 0};      // largest dynamic LDS already enabled for encode / decode
+    bool timing = false;
+    std::vector<EventPair> pending[CIMG_K_COUNT];
+    std::vector<EventPair> free_events;
+    double total_ms[CIMG_K_COUNT] = {0, 0, 0, 0};
+    int64_t launches[CIMG_K_COUNT] = {0, 0, 0, 0};
+    std::string err;
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    int hip(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return 0;
+        return fail(ERR_FAILURE, "%s: %s", what, hipGetErrorString(e));
+    }
+    int reserve(DevBuf& b, size_t bytes)
+    {
+        if (bytes <= b.cap) return 0;
+        if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return hip(e, "hipFree"); }
+        const size_t want = std::max(bytes + bytes / 4, (size_t)4096);
+        int rc = hip(hipMalloc(&b.p, want), "hipMalloc");
+        if (rc) return rc;
+        b.cap = want;
+        return 0;
+    }
+    int reserve(PinBuf& b, size_t bytes)
+    {
+        if (bytes <= b.cap) return 0;
+        if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        const size_t want = std::max(bytes + bytes / 4, (size_t)4096);
+        int rc = hip(hipHostMalloc(&b.p, want, hipHostMallocDefault), "hipHostMalloc");
+        if (rc) return rc;
+        b.cap = want;
+        return 0;
+    }
+    EventPair get_events()
+    {
+        if (!free_events.empty()) { EventPair e = free_events.back(); free_events.pop_back(); return e; }
+        EventPair e{};
+        (void)hipEventCreate(&e.a);
+        (void)hipEventCreate(&e.b);
+        return e;
+    }
+    void drain_timing()
+    {
+        for (int k = 0; k < CIMG_K_COUNT; k++) {
+            for (EventPair& ev : pending[k]) {
+                float ms = 0.f;
+                if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+                    total_ms[k] += ms;
+                    launches[k] += 1;
+                }
+                free_events.push_back(ev);
+            }
+            pending[k].clear();
+        }
+    }
+    template <class Args>
+    int launch(int kid, void (*kernel)(Args), const Args& args, int grid, int block, int lds)
+    {
+        if (grid <= 0) return 0;
+        EventPair ev{};
+        if (timing) { ev = get_events(); (void)hipEventRecord(ev.a, stream); }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3((unsigned)block), (size_t)lds, stream, args);
+        int rc = hip(hipGetLastError(), cimg_kernel_name(kid));
+        if (timing) { (void)hipEventRecord(ev.b, stream); pending[kid].push_back(ev); }
+        return rc;
+    }
+    template <class Args>
+    int allow_lds(void (*kernel)(Args), int which, int bytes)
+    {
+        if (bytes <= max_dyn_lds[which]) return 0;
+        int rc = hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes),
+                     "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+        if (rc) return rc;
+        max_dyn_lds[which] = bytes;
+        return 0;
+    }
+};
+
+extern "C" {
+
+const char* cimg_kernel_name(int k)
+{
+    switch (k) {
+    case CIMG_K_ENCODE: return "cimg_encode_blocks";
+    case CIMG_K_LAYOUT: return "cimg_layout_chunks";
+    case CIMG_K_EMIT: return "cimg_emit_blocks";
+    case CIMG_K_DECODE: return "cimg_decode_blocks";
+    default: return "?";
+    }
+}
+
+void cimg_cparams_init(cimg_cparams* p, int32_t typesize)
+{
+    memset(p, 0, sizeof(*p));
+    p->typesize = typesize;
+    p->clevel = 9;
+    p->blocksize = 32768;
+    p->compcode = CODEC_LZ4;
+    p->splitmode = SPLIT_AUTO;
+    p->filters[5] = FILTER_SHUFFLE;
+}
+
+int cimg_engine_create(int device, cimg_engine** out)
+{
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return ERR_FAILURE;
+    }
+    if (device < 0) { e = hipGetDevice(&device); if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return ERR_FAILURE; } }
+    if (device >= count) { g_create_error = "device index out of range"; return ERR_INVALID_PARAM; }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return ERR_FAILURE; }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return ERR_FAILURE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("libcimg_hip.so is built for gfx950 only; device is ") + prop.gcnArchName;
+        return ERR_FAILURE;
+    }
+    cimg_engine* eng = new cimg_engine();
+    eng->device = device;
+    e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete eng; return ERR_FAILURE; }
+    *out = eng;
+    return 0;
+}
+
+void cimg_engine_destroy(cimg_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    e->drain_timing();
+    for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (DevBuf* b : {&e->descs, &e->recs, &e->layout, &e->scratch, &e->status, &e->stage_raw, &e->stage_comp})
+        if (b->p) (void)hipFree(b->p);
+    for (PinBuf* b : {&e->h_descs, &e->h_out})
+        if (b->p) (void)hipHostFree(b->p);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* cimg_last_error(const cimg_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+void* cimg_engine_stream(cimg_engine* e) { return (void*)e->stream; }
+int cimg_engine_synchronize(cimg_engine* e) { return e->hip(hipStreamSynchronize(e->stream), "hipStreamSynchronize"); }
+
+void* cimg_device_malloc(cimg_engine* e, size_t bytes)
+{
+    void* p = nullptr;
+    (void)hipSetDevice(e->device);
+    if (e->hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return nullptr;
+    return p;
+}
+void cimg_device_free(cimg_engine* e, void* p) { if (p) { (void)hipSetDevice(e->device); (void)hipFree(p); } }
+int cimg_memcpy_h2d(cimg_engine* e, void* d, const void* h, size_t n)
+{
+    int rc = e->hip(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, e->stream), "hipMemcpyAsync(H2D)");
+    return rc ? rc : cimg_engine_synchronize(e);
+}
+int cimg_memcpy_d2h(cimg_engine* e, void* h, const void* d, size_t n)
+{
+    int rc = e->hip(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, e->stream), "hipMemcpyAsync(D2H)");
+    return rc ? rc : cimg_engine_synchronize(e);
+}
+
+void cimg_engine_enable_timing(cimg_engine* e, int on) { e->timing = on != 0; }
+void cimg_engine_reset_timing(cimg_engine* e)
+{
+    (void)hipStreamSynchronize(e->stream);
+    e->drain_timing();
+    for (int k = 0; k < CIMG_K_COUNT; k++) { e->total_ms[k] = 0; e->launches[k] = 0; }
+}
+int cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_t* launches)
+{
+    if (kernel < 0 || kernel >= CIMG_K_COUNT) return ERR_INVALID_PARAM;
+    int rc = cimg_engine_synchronize(e);
+    if (rc) return rc;
+    e->drain_timing();
+    if (total_ms) *total_ms = e->total_ms[kernel];
+    if (launches) *launches = e->launches[kernel];
+    return 0;
+}
+
+static HostCParams to_host(const cimg_cparams* p)
+{
+    HostCParams h;
+    h.typesize = p->typesize; h.clevel = p->clevel; h.blocksize = p->blocksize;
+    h.compcode = p->compcode; h.splitmode = p->splitmode;
+    memcpy(h.filters, p->filters, 6);
+    memcpy(h.filters_meta, p->filters_meta, 6);
+    return h;
+}
+
+int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                               const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
+                               void* d_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
+{
+    if (nchunks <= 0) return 0;
+    if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    (void)hipSetDevice(e->device);
+    EncodePlan plan;
+    int rc = plan_encode_batch(to_host(p), nchunks, raw_off, nbytes, comp_off, destsize, &plan);
+    if (rc < 0) return e->fail(rc, "compress batch rejected by the planner (code %d): codec %d / filter pipeline / block size %d not available on the GPU path",
+                               rc, p->compcode, p->blocksize);
+    const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
+    if ((rc = e->reserve(e->descs, desc_bytes))) return rc;
+    if ((rc = e->reserve(e->h_descs, desc_bytes))) return rc;
+    if ((rc = e->reserve(e->recs, sizeof(StreamRec) * (size_t)plan.total_blocks * plan.cp.streams_per_block))) return rc;
+    if ((rc = e->reserve(e->layout, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
+    if ((rc = e->reserve(e->h_out, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
+    if ((rc = e->reserve(e->scratch, (size_t)plan.total_blocks * plan.cp.slot_bytes + 64))) return rc;
+    memcpy(e->h_descs.p, plan.descs.data(), desc_bytes);
+    if ((rc = e->hip(hipMemcpyAsync(e->descs.p, e->h_descs.p, desc_bytes, hipMemcpyHostToDevice, e->stream), "descs H2D"))) return rc;
+
+    EncodeArgs ea{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
+                  (StreamRec*)e->recs.p, plan.lds_bytes};
+    if (plan.lds_bytes > 0) {
+        if ((rc = e->allow_lds(cimg_encode_blocks, 0, plan.lds_bytes))) return rc;
+        if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_blocks, ea, plan.total_blocks, 256, plan.lds_bytes))) return rc;
+    }
+    AssembleArgs aa{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
+                    (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p};
+    if ((rc = e->launch(CIMG_K_LAYOUT, cimg_layout_chunks, aa, nchunks, 64, 0))) return rc;
+    if ((rc = e->launch(CIMG_K_EMIT, cimg_emit_blocks, aa, plan.total_blocks, 256, 0))) return rc;
+    if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->layout.p, sizeof(ChunkLayout) * (size_t)nchunks, hipMemcpyDeviceToHost, e->stream), "layout D2H"))) return rc;
+    if ((rc = cimg_engine_synchronize(e))) return rc;
+    const ChunkLayout* lay = (const ChunkLayout*)e->h_out.p;
+    for (int i = 0; i < nchunks; i++) cbytes[i] = lay[i].cbytes;
+    return 0;
+}
+
+int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
+                                 const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
+                                 int32_t* status)
+{
+    if (nchunks <= 0) return 0;
+    if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    (void)hipSetDevice(e->device);
+    DecodePlan plan;
+    int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan);
+    if (rc < 0) return e->fail(rc, "decompress batch rejected by the planner (code %d)", rc);
+    const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
+    const size_t st_bytes = sizeof(int32_t) * (size_t)nchunks;
+    if ((rc = e->reserve(e->descs, desc_bytes))) return rc;
+    if ((rc = e->reserve(e->h_descs, desc_bytes))) return rc;
+    if ((rc = e->reserve(e->status, st_bytes))) return rc;
+    if ((rc = e->reserve(e->h_out, st_bytes))) return rc;
+    memcpy(e->h_descs.p, plan.descs.data(), desc_bytes);
+    if ((rc = e->hip(hipMemcpyAsync(e->descs.p, e->h_descs.p, desc_bytes, hipMemcpyHostToDevice, e->stream), "descs H2D"))) return rc;
+    if ((rc = e->hip(hipMemsetAsync(e->status.p, 0, st_bytes, e->stream), "status memset"))) return rc;
+    DecodeArgs da{(const ChunkDesc*)e->descs.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, (int32_t*)e->status.p, plan.lds_bytes};
+    if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
+    if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
+    if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->status.p, st_bytes, hipMemcpyDeviceToHost, e->stream), "status D2H"))) return rc;
+    if ((rc = cimg_engine_synchronize(e))) return rc;
+    const int32_t* st = (const int32_t*)e->h_out.p;
+    int first = 0;
+    for (int i = 0; i < nchunks; i++) {
+        if (status) status[i] = st[i];
+        if (!first && st[i] < 0) first = st[i];
+    }
+    if (first) return e->fail(first, "chunk decode failed with blosc2 error %d", first);
+    return 0;
+}
+
+// ---- host-resident batches: stage through device buffers owned by the engine -----------------------
+int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
+                             const int64_t* raw_off, const int32_t* nbytes, void* h_comp, const int64_t* comp_off,
+                             const int32_t* destsize, int32_t* cbytes)
+{
+    if (nchunks <= 0) return 0;
+    if (!h_raw || !h_comp || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    (void)hipSetDevice(e->device);
+    // pack pixels back to back (16-byte aligned) and give every chunk its full destsize on the device
+    std::vector<int64_t> d_raw_off((size_t)nchunks), d_comp_off((size_t)nchunks);
+    int64_t raw_total = 0, comp_total = 0;
+    bool contiguous = true;
+    for (int i = 0; i < nchunks; i++) {
+        if (nbytes[i] < 0 || destsize[i] < 0) return e->fail(ERR_INVALID_PARAM, "negative size");
+        if (i > 0 && raw_off[i] != raw_off[i - 1] + nbytes[i - 1]) contiguous = false;
+    }
+    for (int i = 0; i < nchunks; i++) {
+        d_raw_off[(size_t)i] = raw_total;
+        raw_total += contiguous ? (int64_t)nbytes[i] : (((int64_t)nbytes[i] + 15) & ~15ll);
+        d_comp_off[(size_t)i] = comp_total;
+        comp_total += ((int64_t)destsize[i] + 63) & ~63ll;
+    }
+    int rc;
+    if ((rc = e->reserve(e->stage_raw, (size_t)raw_total + 64))) return rc;
+    if ((rc = e->reserve(e->stage_comp, (size_t)comp_total + 64))) return rc;
+    const uint8_t* hr = (const uint8_t*)h_raw;
+    if (contiguous) {
+        if ((rc = e->hip(hipMemcpyAsync(e->stage_raw.p, hr + raw_off[0], (size_t)raw_total, hipMemcpyHostToDevice, e->stream), "pixels H2D"))) return rc;
+    } else {
+        for (int i = 0; i < nchunks; i++)
+            if ((rc = e->hip(hipMemcpyAsync((uint8_t*)e->stage_raw.p + d_raw_off[(size_t)i], hr + raw_off[i], (size_t)nbytes[i], hipMemcpyHostToDevice, e->stream), "pixels H2D"))) return rc;
+    }
+    rc = cimg_compress_batch_device(e, p, nchunks, e->stage_raw.p, d_raw_off.data(), nbytes, e->stage_comp.p, d_comp_off.data(), destsize, cbytes);
+    if (rc) return rc;
+    uint8_t* hc = (uint8_t*)h_comp;
+    for (int i = 0; i < nchunks; i++)
+        if (cbytes[i] > 0)
+            if ((rc = e->hip(hipMemcpyAsync(hc + comp_off[i], (uint8_t*)e->stage_comp.p + d_comp_off[(size_t)i], (size_t)cbytes[i], hipMemcpyDeviceToHost, e->stream), "chunk D2H"))) return rc;
+    return cimg_engine_synchronize(e);
+}
+
+int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_comp, const int64_t* comp_off,
+                               void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity, int32_t* status)
+{
+    if (nchunks <= 0) return 0;
+    if (!h_comp || !h_raw || !comp_off || !raw_off || !raw_capacity) return e->fail(ERR_INVALID_PARAM, "null argument");
+    (void)hipSetDevice(e->device);
+    const uint8_t* hc = (const uint8_t*)h_comp;
+    std::vector<int64_t> d_comp_off((size_t)nchunks), d_raw_off((size_t)nchunks);
+    std::vector<int32_t> nb((size_t)nchunks), bs((size_t)nchunks), cb((size_t)nchunks);
+    int64_t comp_total = 0, raw_total = 0;
+    for (int i = 0; i < nchunks; i++) {
+        const uint8_t* c = hc + comp_off[i];
+        int32_t n, cbv, b;
+        memcpy(&n, c + OFF_NBYTES, 4); memcpy(&b, c + OFF_BLOCKSIZE, 4); memcpy(&cbv, c + OFF_CBYTES, 4);
+        if (c[0] > 5) return e->fail(ERR_VERSION_SUPPORT, "chunk %d: format version %d", i, c[0]);
+        if (cbv < HEADER_LEN || b <= 0 || (n > 0 && b > n) || c[OFF_TYPESIZE] == 0) return e->fail(ERR_INVALID_HEADER, "chunk %d: invalid header", i);
+        if (n > raw_capacity[i]) return e->fail(ERR_WRITE_BUFFER, "chunk %d: needs %d bytes, buffer has %d", i, n, raw_capacity[i]);
+        nb[(size_t)i] = n; bs[(size_t)i] = b; cb[(size_t)i] = cbv;
+        d_comp_off[(size_t)i] = comp_total; comp_total += ((int64_t)cbv + 63) & ~63ll;
+        d_raw_off[(size_t)i] = raw_total; raw_total += ((int64_t)n + 15) & ~15ll;
+    }
+    int rc;
+    if ((rc = e->reserve(e->stage_comp, (size_t)comp_total + 64))) return rc;
+    if ((rc = e->reserve(e->stage_raw, (size_t)raw_total + 64))) return rc;
+    for (int i = 0; i < nchunks; i++)
+        if ((rc = e->hip(hipMemcpyAsync((uint8_t*)e->stage_comp.p + d_comp_off[(size_t)i], hc + comp_off[i], (size_t)cb[(size_t)i], hipMemcpyHostToDevice, e->stream), "chunk H2D"))) return rc;
+    // chunks with nbytes == 0 carry no blocks; blocksize must still be positive for the planner
+    rc = cimg_decompress_batch_device(e, nchunks, e->stage_comp.p, d_comp_off.data(), nb.data(), bs.data(), e->stage_raw.p, d_raw_off.data(), status);
+    if (rc) return rc;
+    uint8_t* hr = (uint8_t*)h_raw;
+    for (int i = 0; i < nchunks; i++)
+        if (nb[(size_t)i] > 0)
+            if ((rc = e->hip(hipMemcpyAsync(hr + raw_off[i], (uint8_t*)e->stage_raw.p + d_raw_off[(size_t)i], (size_t)nb[(size_t)i], hipMemcpyDeviceToHost, e->stream), "pixels D2H"))) return rc;
+    return cimg_engine_synchronize(e);
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+// plan.h -- host-side chunk geometry: what blosc2_compress_ctx derives from (cparams, srcsize)
+// before it touches a byte (oracle/chunk.c: orc_chunk_geometry is the
+// checker's copy of the same rules).  Pure C++, shared by the engine and the emulator.
+#pragma once
+#include "codec_types.h"
+#include <stdint.h>
+#include <vector>
+
+namespace cimg {
+
+struct HostCParams {
+    int32_t typesize = 1;
+    int32_t clevel = 9;
+    int32_t blocksize = 32768;                 // constants.h:11 default
+    int32_t compcode = CODEC_LZ4;              // channel.h:101 default
+    int32_t splitmode = SPLIT_AUTO;            // wrapper.h:328,353
+    uint8_t filters[6] = {0, 0, 0, 0, 0, FILTER_SHUFFLE};   // BLOSC2_CPARAMS_DEFAULTS
+    uint8_t filters_meta[6] = {0, 0, 0, 0, 0, 0};
+};
+
+inline int compformat_of(int compcode)
+{
+    switch (compcode) {
+    case CODEC_BLOSCLZ: return 0;
+    case CODEC_LZ4: case CODEC_LZ4HC: return 1;
+    case CODEC_ZLIB: return 3;
+    case CODEC_ZSTD: return 4;
+    default: return -1;
+    }
+}
+
+// the single filter the kernels implement: one of none/shuffle/bitshuffle, in the last pipeline slot
+inline int single_filter(const HostCParams& p, int* filter)
+{
+    for (int i = 0; i < 5; i++) if (p.filters[i] != 0) return ERR_CODEC_SUPPORT;
+    if (p.filters[5] > FILTER_BITSHUFFLE) return ERR_CODEC_SUPPORT;
+    *filter = p.filters[5];
+    return 0;
+}
+
+inline bool wants_split(const HostCParams& p, int typesize, int blocksize)
+{
+    if (p.splitmode == SPLIT_ALWAYS) return true;
+    if (p.splitmode == SPLIT_NEVER) return false;
+    const bool fast = p.compcode == CODEC_BLOSCLZ || p.compcode == CODEC_LZ4 || (p.compcode == CODEC_ZSTD && p.clevel <= 5);
+    bool shuffle = false;
+    for (int i = 0; i < 6; i++) shuffle |= p.filters[i] == FILTER_SHUFFLE;
+    return fast && shuffle && typesize <= MAX_STREAMS && blocksize / typesize >= MIN_BUFFERSIZE;
+}
+
+// fills everything in `d` except raw_off / comp_off / blk0; returns 0 or a blosc2 error code
+inline int plan_chunk(const HostCParams& p, int32_t nbytes, int32_t destsize, ChunkDesc* d)
+{
+    *d = ChunkDesc{};
+    if (nbytes < 0) return ERR_MAX_BUFSIZE;
+    if (destsize < HEADER_LEN) return ERR_MAX_BUFSIZE;
+    if (p.clevel < 0 || p.clevel > 9) return ERR_CODEC_PARAM;
+    if (compformat_of(p.compcode) < 0) return ERR_CODEC_SUPPORT;
+    int ts = p.typesize;
+    if (ts <= 0) return ERR_INVALID_PARAM;
+    if (ts > 255) ts = 1;
+    int bs;
+    if (nbytes < ts) {
+        bs = 1;
+    } else {
+        if (p.blocksize <= 0) return ERR_INVALID_PARAM;     // automatic block size is not on the path
+        bs = p.blocksize;
+        if (bs > nbytes) bs = nbytes;
+        if (bs > ts) bs = bs / ts * ts;
+    }
+    d->nbytes = nbytes;
+    d->destsize = destsize;
+    d->blocksize = bs;
+    d->nblocks = nbytes / bs;
+    d->leftover = nbytes % bs;
+    if (d->leftover) d->nblocks++;
+    d->memcpyed = (p.clevel == 0 || nbytes < MIN_BUFFERSIZE) ? 1 : 0;
+    d->flags = FLAG_SHUFFLE | FLAG_BITSHUFFLE;
+    if (d->memcpyed) {
+        d->flags |= FLAG_MEMCPYED;
+    } else {
+        d->split = wants_split(p, ts, bs) ? 1 : 0;
+        if (!d->split) d->flags |= FLAG_DONT_SPLIT;
+        d->flags |= compformat_of(p.compcode) << 5;
+    }
+    if (d->split) d->nstreams = d->leftover ? (d->nblocks - 1) * ts + 1 : d->nblocks * ts;
+    else d->nstreams = d->nblocks;
+    return 0;
+}
+
+}  // namespace cimg
+
+// ---- batch plans (shared by the HIP engine and the emulator) -------------------------------------
+#include "decode_kernel.h"
+#include "encode_kernel.h"
+
+namespace cimg {
+
+struct EncodePlan {
+    std::vector<ChunkDesc> descs;
+    CodecParams cp{};
+    int32_t total_blocks = 0;
+    int32_t lds_bytes = 0;
+};
+
+enum : int { MAX_LDS_BYTES = 160 * 1024 };
+
+inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* raw_off, const int32_t* nbytes,
+                             const int64_t* comp_off, const int32_t* destsize, EncodePlan* plan)
+{
+    plan->descs.resize((size_t)nchunks);
+    int filter = 0;
+    int rc = single_filter(p, &filter);
+    if (rc < 0) return rc;
+    if (p.compcode != CODEC_LZ4) return ERR_CODEC_SUPPORT;     // blosclz/lz4hc/zstd: not built yet
+    if (filter == FILTER_BITSHUFFLE) return ERR_CODEC_SUPPORT;  // config-3 extension: not built yet
+    CodecParams& cp = plan->cp;
+    cp.typesize = p.typesize > 255 ? 1 : p.typesize;
+    cp.clevel = p.clevel;
+    cp.compcode = p.compcode;
+    cp.filter = filter;
+    cp.accel = 10 - p.clevel;
+    cp.max_blocksize = 0;
+    cp.streams_per_block = 1;
+    int32_t blk = 0, lds = 0;
+    for (int i = 0; i < nchunks; i++) {
+        ChunkDesc& d = plan->descs[(size_t)i];
+        rc = plan_chunk(p, nbytes[i], destsize[i], &d);
+        if (rc < 0) return rc;
+        d.raw_off = raw_off[i];
+        d.comp_off = comp_off[i];
+        d.blk0 = blk;
+        blk += d.nblocks;
+        if (d.blocksize > cp.max_blocksize) cp.max_blocksize = d.blocksize;
+        if (d.split) cp.streams_per_block = cp.typesize;
+        if (!d.memcpyed) {
+            const int neblock_max = d.split ? d.blocksize / cp.typesize : d.blocksize;
+            if (neblock_max > LZ4_MAX_INPUT_U16) return ERR_CODEC_SUPPORT;   // byU32 LZ4 regime: not built
+            int need = encode_lds_bytes(d.blocksize, cp.typesize, d.split != 0);
+            if (d.split && d.leftover) {
+                const int n2 = encode_lds_bytes(d.leftover, cp.typesize, false);
+                if (n2 > need) need = n2;
+            }
+            if (need > lds) lds = need;
+        }
+    }
+    if (lds > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
+    plan->total_blocks = blk;
+    plan->lds_bytes = lds;
+    cp.slot_bytes = (cp.max_blocksize + 63) & ~63;
+    return 0;
+}
+
+struct DecodePlan {
+    std::vector<ChunkDesc> descs;
+    int32_t total_blocks = 0;
+    int32_t lds_bytes = 0;
+};
+
+inline int decode_lds_bound(int blocksize)
+{
+    int m = 0;
+    for (int ts = 1; ts <= MAX_STREAMS; ts++) { const int v = decode_lds_bytes(blocksize, ts); if (v > m) m = v; }
+    return m;
+}
+
+// nbytes / blocksize come from the chunk headers (the host reads them; blosc2_cbuffer_sizes)
+inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t* nbytes, const int32_t* blocksize,
+                             const int64_t* raw_off, DecodePlan* plan)
+{
+    plan->descs.resize((size_t)nchunks);
+    int32_t blk = 0, lds = 0;
+    for (int i = 0; i < nchunks; i++) {
+        ChunkDesc& d = plan->descs[(size_t)i];
+        d = ChunkDesc{};
+        if (nbytes[i] < 0 || blocksize[i] <= 0 || (nbytes[i] > 0 && blocksize[i] > nbytes[i])) return ERR_INVALID_HEADER;
+        d.raw_off = raw_off[i];
+        d.comp_off = comp_off[i];
+        d.nbytes = nbytes[i];
+        d.blocksize = blocksize[i];
+        d.nblocks = nbytes[i] / blocksize[i];
+        d.leftover = nbytes[i] % blocksize[i];
+        if (d.leftover) d.nblocks++;
+        d.blk0 = blk;
+        blk += d.nblocks;
+        const int need = decode_lds_bound(d.blocksize);
+        if (need > lds) lds = need;
+    }
+    if (lds > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
+    plan->total_blocks = blk;
+    plan->lds_bytes = lds;
+    return 0;
+}
+
+}  // namespace cimg

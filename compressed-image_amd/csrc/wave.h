@@ -1,0 +1,153 @@
+// wave.h -- the 64-lane wavefront vocabulary the codec kernels are written in.
+//
+// The kernels in this directory are written once, in an explicit "wave-uniform control flow +
+// per-lane data" style:
+//   * plain C++ variables are wave-uniform (they live in SGPRs on gfx950),
+//   * LV<T> variables hold one value per lane, touched only inside FOR_LANES(l) { ... x[l] ... },
+//   * cross-lane traffic goes through ballot()/readlane()/wave_*().
+// Compiled by hipcc for gfx950 this collapses to ordinary SIMT code (LV<T> is a single register,
+// FOR_LANES runs once with l = lane id).  Compiled with -DCIMG_EMULATE by g++ the same source runs
+// on the host with LV<T> = T[64] and FOR_LANES = a 64-iteration loop.  The emulated build exists only
+// so that tests/ can exercise the kernel *logic* in a container without a GPU (tests/emu); it is
+// never linked into libcimg_hip.so and the product has no CPU path.
+//
+// Rules that keep both builds equivalent:
+//   R1  A FOR_LANES body never reads an LDS/global location that another lane writes in the same
+//       body (on the GPU all lanes read before any lane writes; the emulator runs lanes in turn).
+//   R2  Bodies that store to possibly-colliding addresses use FOR_LANES_W: the emulator then visits
+//       lanes in a test-selected order (ascending / descending / shuffled) so that code depending on
+//       which colliding lane "wins" is caught.
+//   R3  Everything outside FOR_LANES is wave-uniform.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#ifdef CIMG_EMULATE
+// ------------------------------------------------------------------------------------------------
+//  host emulation
+// ------------------------------------------------------------------------------------------------
+#define CIMG_DEV inline
+#define CIMG_HD inline
+
+namespace cimg {
+
+template <class T> struct LV {
+    T v[64];
+    T& operator[](int l) { return v[l]; }
+    const T& operator[](int l) const { return v[l]; }
+};
+
+extern int g_emu_write_order;                 // 0 ascending, 1 descending, 2 shuffled
+inline int emu_lane(int i)
+{
+    if (g_emu_write_order == 1) return 63 - i;
+    if (g_emu_write_order == 2) return (i * 37 + 11) & 63;     // 37 is odd -> a permutation of 0..63
+    return i;
+}
+#define FOR_LANES(l) for (int l = 0; l < 64; ++l)
+#define FOR_LANES_W(l) for (int l##_i = 0, l = ::cimg::emu_lane(0); l##_i < 64; ++l##_i, l = ::cimg::emu_lane(l##_i & 63))
+
+inline uint64_t ballot(const LV<bool>& p)
+{
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) if (p.v[l]) m |= 1ull << l;
+    return m;
+}
+template <class T> inline T readlane(const LV<T>& x, int lane) { return x.v[lane & 63]; }
+inline int uni(int x) { return x; }
+inline uint32_t uni(uint32_t x) { return x; }
+inline int ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3))); }
+// exclusive prefix sum across the wave
+inline void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
+{
+    int run = 0;
+    for (int l = 0; l < 64; ++l) { out.v[l] = run; run += x.v[l]; }
+    total = run;
+}
+inline int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
+inline void wave_sync_lds() {}
+inline void mem_fence_block() {}
+
+}  // namespace cimg
+
+#else
+// ------------------------------------------------------------------------------------------------
+//  gfx950 device build
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#define CIMG_DEV __device__ __forceinline__
+#define CIMG_HD __host__ __device__ __forceinline__
+
+namespace cimg {
+
+template <class T> struct LV {
+    T v;
+    CIMG_DEV T& operator[](int) { return v; }
+    CIMG_DEV const T& operator[](int) const { return v; }
+};
+
+#define FOR_LANES(l) for (int l = (int)__lane_id(), l##_once = 1; l##_once; l##_once = 0)
+#define FOR_LANES_W(l) FOR_LANES(l)
+
+CIMG_DEV uint64_t ballot(const LV<bool>& p) { return __ballot(p.v); }
+template <class T> CIMG_DEV T readlane(const LV<T>& x, int lane)
+{
+    static_assert(sizeof(T) <= 4, "readlane moves one dword");
+    return (T)__builtin_amdgcn_readlane((int)x.v, lane);
+}
+CIMG_DEV int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+CIMG_DEV uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+CIMG_DEV int ctz64(uint64_t m) { return m ? (int)__builtin_ctzll(m) : 64; }
+CIMG_DEV int popc64(uint64_t m) { return (int)__builtin_popcountll(m); }
+CIMG_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+CIMG_DEV void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
+{
+    int v = x.v;
+    const int lane = (int)__lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    total = __builtin_amdgcn_readlane(v, 63);
+    out.v = v - x.v;
+}
+CIMG_DEV int wave_max(const LV<int>& x)
+{
+    int v = x.v;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int n = __shfl_xor(v, d); v = n > v ? n : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+}  // namespace cimg
+#endif
+
+namespace cimg {
+
+// ---- byte helpers shared by both builds ----------------------------------------------------------
+CIMG_DEV uint32_t ld32u(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+CIMG_DEV int32_t ld32s(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }
+CIMG_DEV void st32(uint8_t* p, int32_t v) { memcpy(p, &v, 4); }
+
+struct u128 { uint32_t x, y, z, w; };
+CIMG_DEV u128 ld128u(const uint8_t* p) { u128 v; memcpy(&v, p, 16); return v; }      // any alignment
+CIMG_DEV void st128u(uint8_t* p, const u128& v) { memcpy(p, &v, 16); }               // any alignment
+CIMG_DEV u128 ld128a(const uint8_t* p) { return *reinterpret_cast<const u128*>(__builtin_assume_aligned(p, 16)); }
+CIMG_DEV void st128a(uint8_t* p, const u128& v) { *reinterpret_cast<u128*>(__builtin_assume_aligned(p, 16)) = v; }
+
+// unaligned 32-bit read from LDS built from two aligned dword reads (always legal on the LDS path)
+CIMG_DEV uint32_t lds_ld32u(const uint8_t* lds, int off)
+{
+    const int a = off & ~3;
+    const uint32_t lo = *reinterpret_cast<const uint32_t*>(lds + a);
+    const uint32_t hi = *reinterpret_cast<const uint32_t*>(lds + a + 4);
+    return alignbyte(hi, lo, (uint32_t)off & 3u);
+}
+
+CIMG_HD int imin(int a, int b) { return a < b ? a : b; }
+CIMG_HD int imax(int a, int b) { return a > b ? a : b; }
+
+}  // namespace cimg

@@ -1,0 +1,97 @@
+/*
+ * cimg_hip.h -- C ABI of libcimg_hip.so, the MI355X (gfx950) chunk codec engine.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) include/blosc2.h -- the eleven c-blosc2 symbols the reference binds
+ *      (compressed/blosc2/wrapper.h, blosc2/util.h, blosc2/schunk.h:113), same names and argument
+ *      meaning, so the reference's own headers link against this library instead of c-blosc2.
+ *
+ *  (2) this header -- the *batched* extension.  One blosc2_compress_ctx call is one <= 4 MiB chunk
+ *      (wrapper.h:139,172), far too little to fill 256 CUs; the reference's loops over chunks
+ *      (schunk.h:85-104, schunk.h:130-138) and over channels (image.h:119-159, 1307-1315) become one
+ *      call here.  Plain pointers and sizes only; no HIP or torch types.
+ *
+ * All functions return 0 (or a non-negative size) on success and a negative c-blosc2 error code
+ * (include/blosc2.h, BLOSC2_ERROR_*) on failure; cimg_last_error() gives the text.  An engine is
+ * not thread-safe (the reference's contexts are not either, channel.h:511-513).
+ */
+#ifndef CIMG_HIP_H
+#define CIMG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cimg_engine cimg_engine;
+
+/* Mirrors the blosc2_cparams fields the reference sets (wrapper.h:325-332, 350-356) plus the filter
+ * pipeline it inherits from BLOSC2_CPARAMS_DEFAULTS. */
+typedef struct cimg_cparams {
+    int32_t typesize;        /* sizeof(T) */
+    int32_t clevel;          /* 0..9 */
+    int32_t blocksize;       /* bytes; constants.h:11 default 32768 */
+    int32_t compcode;        /* BLOSC_LZ4 = 1 (BLOSC_BLOSCLZ = 0, BLOSC_LZ4HC = 2, BLOSC_ZSTD = 5) */
+    int32_t splitmode;       /* BLOSC_AUTO_SPLIT = 3 */
+    uint8_t filters[6];      /* default {0,0,0,0,0,BLOSC_SHUFFLE} */
+    uint8_t filters_meta[6];
+} cimg_cparams;
+
+void cimg_cparams_init(cimg_cparams* p, int32_t typesize);   /* the reference's defaults: lz4, level 9, 32 KiB blocks */
+
+/* ---- engine ---------------------------------------------------------------------------------------- */
+int  cimg_engine_create(int device, cimg_engine** out);      /* device < 0: current device */
+void cimg_engine_destroy(cimg_engine* e);
+const char* cimg_last_error(const cimg_engine* e);            /* e may be NULL: last create() failure */
+int  cimg_engine_synchronize(cimg_engine* e);
+void* cimg_engine_stream(cimg_engine* e);                     /* the hipStream_t every launch goes to */
+
+/* ---- device-resident batches -----------------------------------------------------------------------
+ * Chunk i's pixels live at d_raw + raw_off[i] (nbytes[i] bytes), its blosc2 chunk at
+ * d_comp + comp_off[i] with capacity destsize[i] (what the reference passes as the dest span:
+ * nominal chunk size + BLOSC2_MAX_OVERHEAD, schunk.h:73).  Offset / size arrays are HOST arrays.
+ * cbytes[i] receives what blosc2_compress_ctx would return for that chunk (0 = does not fit).
+ * The call returns after the results are on the host (one stream sync). */
+int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                               const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
+                               void* d_comp, const int64_t* comp_off, const int32_t* destsize,
+                               int32_t* cbytes);
+/* nbytes[i] / blocksize[i] are the values in chunk i's header (blosc2_cbuffer_sizes); status[i]
+ * receives 0 or the blosc2 error code of that chunk. Returns the first non-zero status, or 0. */
+int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks,
+                                 const void* d_comp, const int64_t* comp_off,
+                                 const int32_t* nbytes, const int32_t* blocksize,
+                                 void* d_raw, const int64_t* raw_off, int32_t* status);
+
+/* ---- host-resident batches (H2D + kernels + D2H inside) ------------------------------------------ */
+int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                             const void* h_raw, const int64_t* raw_off, const int32_t* nbytes,
+                             void* h_comp, const int64_t* comp_off, const int32_t* destsize,
+                             int32_t* cbytes);
+/* Sizes are read from the chunk headers in host memory. */
+int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks,
+                               const void* h_comp, const int64_t* comp_off,
+                               void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity,
+                               int32_t* status);
+
+/* ---- device memory without HIP headers ------------------------------------------------------------ */
+void* cimg_device_malloc(cimg_engine* e, size_t bytes);
+void  cimg_device_free(cimg_engine* e, void* p);
+int   cimg_memcpy_h2d(cimg_engine* e, void* d_dst, const void* h_src, size_t bytes);
+int   cimg_memcpy_d2h(cimg_engine* e, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- kernel timing (HIP events on the engine's stream) ------------------------------------------- */
+enum { CIMG_K_ENCODE = 0, CIMG_K_LAYOUT = 1, CIMG_K_EMIT = 2, CIMG_K_DECODE = 3, CIMG_K_COUNT = 4 };
+void cimg_engine_enable_timing(cimg_engine* e, int on);
+void cimg_engine_reset_timing(cimg_engine* e);
+/* total milliseconds and launch count of one kernel since the last reset (syncs the stream) */
+int  cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_t* launches);
+const char* cimg_kernel_name(int kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+// tests/emu/emu.cpp -- TEST INFRASTRUCTURE: the gfx950 kernel bodies compiled for the host with the
+// 64-lane emulator of csrc/wave.h, so the kernel *logic* (window commit rules, in-place LZ4 decode,
+// layout walk) can be checked against the oracle in a container that has no GPU.  Never linked into
+// libcimg_hip.so; nothing in the product loads it.
+#define CIMG_EMULATE 1
+#include "plan.h"
+#include "assemble_kernel.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace cimg { int g_emu_write_order = 0; }
+using namespace cimg;
+
+extern "C" {
+
+void emu_set_write_order(int o) { g_emu_write_order = o; }
+
+struct EmuCParams {
+    int32_t typesize, clevel, blocksize, compcode, splitmode;
+    uint8_t filters[6], filters_meta[6];
+};
+
+static HostCParams to_host(const EmuCParams* p)
+{
+    HostCParams h;
+    h.typesize = p->typesize; h.clevel = p->clevel; h.blocksize = p->blocksize;
+    h.compcode = p->compcode; h.splitmode = p->splitmode;
+    memcpy(h.filters, p->filters, 6); memcpy(h.filters_meta, p->filters_meta, 6);
+    return h;
+}
+
+int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, const int64_t* raw_off,
+                       const int32_t* nbytes, uint8_t* comp, const int64_t* comp_off, const int32_t* destsize,
+                       int32_t* cbytes)
+{
+    EncodePlan plan;
+    int rc = plan_encode_batch(to_host(p), nchunks, raw_off, nbytes, comp_off, destsize, &plan);
+    if (rc < 0) return rc;
+    std::vector<uint8_t> scratch((size_t)plan.total_blocks * plan.cp.slot_bytes + 64, 0xEE);
+    std::vector<StreamRec> recs((size_t)plan.total_blocks * plan.cp.streams_per_block);
+    std::vector<ChunkLayout> layout((size_t)nchunks);
+    std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
+    EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), plan.lds_bytes};
+    for (int b = 0; b < plan.total_blocks; b++) {
+        memset(lds.data(), 0xCD, lds.size());
+        EncodeBlock blk(ea, lds.data(), b);
+        for (int w = 0; w < 4; w++) blk.phase_a(w);
+        for (int w = 0; w < 4; w++) blk.phase_b(w);
+    }
+    AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data()};
+    for (int c = 0; c < nchunks; c++) { LayoutChunk lc(aa, c); lc.run(); }
+    for (int b = 0; b < plan.total_blocks; b++) { EmitBlock eb(aa, b); for (int w = 0; w < 4; w++) eb.run(w); }
+    for (int c = 0; c < nchunks; c++) cbytes[c] = layout[(size_t)c].cbytes;
+    return 0;
+}
+
+int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_off, const int32_t* nbytes,
+                         const int32_t* blocksize, uint8_t* raw, const int64_t* raw_off, int32_t* status)
+{
+    DecodePlan plan;
+    int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan);
+    if (rc < 0) return rc;
+    memset(status, 0, sizeof(int32_t) * (size_t)nchunks);
+    std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
+    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes};
+    for (int b = 0; b < plan.total_blocks; b++) {
+        memset(lds.data(), 0xCD, lds.size());
+        DecodeBlock blk(da, lds.data(), b);
+        // each wave keeps its own copy of the uniform walk results on the GPU; emulate that
+        DecodeBlock w0 = blk, w1 = blk, w2 = blk, w3 = blk;
+        DecodeBlock* ws[4] = {&w0, &w1, &w2, &w3};
+        for (int w = 0; w < 4; w++) ws[w]->phase_a(w);
+        for (int w = 0; w < 4; w++) ws[w]->phase_b(w);
+    }
+    return 0;
+}
+
+// single-stream entry points for the LZ4 wave codec
+int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, int* need)
+{
+    std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
+    memcpy(lds.data(), src, (size_t)n);
+    int nd = 0;
+    const int r = lz4_encode_wave(lds.data(), lds.data() + round16(n) + 32, n, dst, cap, accel, nd);
+    if (need) *need = nd;
+    return r;
+}
+
+int emu_lz4_decode(const uint8_t* src, int csize, uint8_t* dst, int n)
+{
+    const int rs = region_stride(n);
+    std::vector<uint8_t> lds((size_t)rs + 64, 0xCD);
+    const int park = rs - round16(csize);
+    memcpy(lds.data() + park, src, (size_t)csize);
+    const int rc = lz4_decode_wave(lds.data(), 0, n, park, csize, rs + 32);
+    memcpy(dst, lds.data(), (size_t)n);
+    return rc;
+}
+
+}  // extern "C"

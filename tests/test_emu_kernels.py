@@ -1,0 +1,131 @@
+"""Kernel LOGIC on CPU: the gfx950 kernel bodies (csrc/*_kernel.h) compiled for the host lane emulator
+(tests/emu) must reproduce the oracle bit for bit -- compressed bytes and pixels.  These tests do not
+replace the `-m gpu` parity tests; they make sure the windowed LZ4 search, the in-place LZ4 decode
+and the layout walk are right before any GPU time is spent.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _emu as E
+import _oracle as O
+from cimg import synth
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "lz4_kat.npz"))
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_wave_lz4_encoder_matches_liblz4(kat, order):
+    """Every limited-output golden vector, under three orders of resolving colliding LDS writes."""
+    E.set_write_order(order)
+    try:
+        n = 0
+        for key in kat["cases"]:
+            key = str(key)
+            name, a, c = key.split("|")
+            src = kat["in|" + name]
+            cap = int(c[1:])
+            if cap >= src.size + src.size // 255 + 16:
+                continue                       # the wave encoder is the limited-output form blosc2 uses
+            r, out, _ = E.lz4_encode(src, cap, int(a[1:]))
+            assert r == int(kat["ret|" + key]), key
+            assert out == kat["out|" + key].tobytes(), key
+            n += 1
+        assert n > 600
+    finally:
+        E.set_write_order(0)
+
+
+def test_wave_lz4_need_matches_liblz4(kat):
+    for key in (k for k in kat.files if k.startswith("need|")):
+        _, name, a = key.split("|")
+        src = kat["in|" + name]
+        r, _, need = E.lz4_encode(src, src.size, int(a[1:]))
+        if r > 0:
+            assert need == int(kat[key]), key
+
+
+def test_wave_lz4_decoder_inverts_golden_streams(kat):
+    n = 0
+    for key in kat["cases"]:
+        key = str(key)
+        if int(kat["ret|" + key]) <= 0:
+            continue
+        src = kat["in|" + key.split("|")[0]]
+        rc, dec = E.lz4_decode(kat["out|" + key], src.size)
+        assert rc == 0 and dec == src.tobytes(), key
+        n += 1
+    assert n > 400
+
+
+def test_wave_lz4_decoder_rejects_damage():
+    src = np.resize(np.arange(50, dtype=np.uint8), 4000)
+    r, comp = O.lz4_compress(src)
+    assert E.lz4_decode(comp, 4000)[0] == 0
+    assert E.lz4_decode(comp[:-3], 4000)[0] < 0
+    assert E.lz4_decode(comp, 3999)[0] < 0
+    assert E.lz4_decode(comp, 4001)[0] < 0
+
+
+def _check_batch(dtype, arr, chunk, blocksize=32768, destsize=None, order=0):
+    it = np.dtype(dtype).itemsize
+    raw = arr.view(np.uint8).ravel()
+    sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
+    dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
+    E.set_write_order(order)
+    try:
+        rc, cb, chunks = E.compress_batch(E.cparams(it, blocksize=blocksize), raw, sizes, dsz)
+    finally:
+        E.set_write_order(0)
+    assert rc == 0
+    po = O.cparams(it, blocksize=blocksize)
+    off = 0
+    for i, s in enumerate(sizes):
+        r, c = O.compress(po, raw[off:off + s], destsize=dsz[i])
+        assert cb[i] == r and chunks[i] == c, (np.dtype(dtype).name, i)
+        off += s
+    live = [(c, s) for c, s in zip(chunks, sizes) if len(c)]
+    if live:
+        rc, st, outs = E.decompress_batch([c for c, _ in live], [s for _, s in live],
+                                          [O.cbuffer_sizes(c)[2] for c, _ in live], misalign=3)
+        assert rc == 0 and not any(st)
+        assert b"".join(o.tobytes() for o in outs) == b"".join(
+            raw[sum(sizes[:i]):sum(sizes[:i + 1])].tobytes() for i, c in enumerate(chunks) if len(c))
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float16, np.uint32, np.float32])
+@pytest.mark.parametrize("family", ["tiled", "zero", "random", "natural"])
+def test_chunk_pipeline_equals_oracle(dtype, family):
+    arr = getattr(synth, family + "_channel")(dtype, 1024, 100)
+    it = np.dtype(dtype).itemsize
+    _check_batch(dtype, arr, 40000 // it * it)         # ragged: 1 full + leftover block per chunk, short last chunk
+
+
+def test_chunk_pipeline_other_typesizes_and_blocks():
+    rng = np.random.default_rng(3)
+    a = (rng.integers(0, 40, 6000, dtype=np.uint64) * 0x0101010101).astype(np.uint64)      # typesize 8
+    _check_batch(np.uint64, a, 16384, blocksize=4096)
+    _check_batch(np.uint16, synth.natural_channel(np.uint16, 300, 41), 5000, blocksize=256)   # tiny blocks
+    _check_batch(np.uint8, synth.natural_channel(np.uint8, 333, 77), 9999, blocksize=1000)     # odd sizes
+    _check_batch(np.uint32, np.arange(50, dtype=np.uint32), 4096)                            # single tiny chunk
+    _check_batch(np.uint8, np.arange(20, dtype=np.uint8), 4096)                              # < 32 bytes: memcpyed
+
+
+def test_chunk_pipeline_destsize_rules_collision_orders():
+    rng = np.random.default_rng(8)
+    noisy = rng.integers(0, 65536, 20000, dtype=np.uint16)
+    noisy[3000:9000] = 7
+    for destsize in (40000 + 32, 39000, 36000, 30000, 20100, 200):
+        _check_batch(np.uint16, noisy, 40000, blocksize=4096, destsize=destsize, order=destsize % 3)
+
+
+def test_reference_known_answers_through_kernels():
+    """iota / constant planes of the reference's OIIO-free tests."""
+    for dt in (np.uint8, np.uint16, np.uint32, np.float32):
+        _check_batch(dt, np.arange(4096).astype(dt), 256, blocksize=64)       # test_schunk.cpp:39-75
+    for v in (255, 0, 199, 12):
+        _check_batch(np.uint16, np.full(64 * 16, v, np.uint16), 768, blocksize=256)   # test_image.cpp chunk 768

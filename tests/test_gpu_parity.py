@@ -1,0 +1,187 @@
+"""Parity tests proper: the HIP kernels, called through the C ABI (libcimg_hip.so), against the oracle.
+
+Bit-exact compressed bytes AND bit-exact pixels on the same seeded inputs, the liblz4 golden vectors
+pushed through the GPU encoder, the reference's own known-answer cases, edge cases, and the BASELINE
+configs[1] geometry at full size.  Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from cimg import hip, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = hip.Engine(0)
+    yield e
+    e.close()
+
+
+def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9):
+    it = np.dtype(dtype).itemsize
+    raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
+    sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
+    dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
+    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize), raw, sizes, dsz)
+    po = O.cparams(it, clevel=clevel, blocksize=blocksize)
+    off = 0
+    for i, s in enumerate(sizes):
+        r, want = O.compress(po, raw[off:off + s], destsize=dsz[i])
+        assert len(chunks[i]) == r, (np.dtype(dtype).name, i, len(chunks[i]), r)
+        if chunks[i] != want:
+            k = next(j for j, (a, b) in enumerate(zip(chunks[i], want)) if a != b)
+            raise AssertionError(f"{np.dtype(dtype).name} chunk {i}: first differing byte at {k} of {r}")
+        off += s
+    live = [c for c in chunks if c]
+    if live:
+        outs, status = eng.decompress_host(live)
+        assert not status.any()
+        want = b"".join(raw[sum(sizes[:i]):sum(sizes[:i + 1])].tobytes() for i, c in enumerate(chunks) if c)
+        assert b"".join(o.tobytes() for o in outs) == want
+    return chunks
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float16, np.uint32, np.float32])
+@pytest.mark.parametrize("family", ["tiled", "zero", "random", "natural"])
+def test_bytes_and_pixels_equal_oracle(eng, dtype, family):
+    arr = getattr(synth, family + "_channel")(dtype, 1024, 300)
+    it = np.dtype(dtype).itemsize
+    _roundtrip(eng, dtype, arr, 4 * 1024 * 1024 // (1024 * it) * 1024 * it)      # scanline-aligned 4 MiB chunks
+    _roundtrip(eng, dtype, arr[:100], 40000 // it * it)                          # ragged: leftover blocks, short last chunk
+
+
+def test_liblz4_golden_vectors_through_the_gpu_encoder(eng, golden_dir):
+    """typesize 1, no filter, block = whole chunk: the chunk's single stream IS the LZ4 call."""
+    kat = np.load(os.path.join(golden_dir, "lz4_kat.npz"))
+    names = sorted({str(k).split("|")[0] for k in kat["cases"]})
+    names = [n for n in names if 32 <= kat["in|" + n].size <= 65536]
+    for clevel, accel in ((9, 1), (5, 5)):
+        raw = np.concatenate([kat["in|" + n] for n in names])
+        sizes = [int(kat["in|" + n].size) for n in names]
+        p = hip.cparams(1, clevel=clevel, blocksize=65536, filters=(0, 0, 0, 0, 0, 0), splitmode=2)
+        chunks = eng.compress_host(p, raw, sizes, [s + 4096 for s in sizes])
+        checked = 0
+        for n, c, s in zip(names, chunks, sizes):
+            src = kat["in|" + n]
+            if (src == src[0]).all():
+                continue                                            # run token, LZ4 not called
+            key = f"{n}|a{accel}|c{s}"
+            ret = int(kat["ret|" + key])
+            (cs,) = struct.unpack_from("<i", c, 32 + 4)
+            if ret == 0 or ret == s:
+                assert cs == s and c[40:40 + s] == src.tobytes(), key
+            else:
+                assert cs == ret and c[40:40 + cs] == kat["out|" + key].tobytes(), key
+            checked += 1
+        assert checked > 50
+        outs, status = eng.decompress_host(chunks)
+        assert not status.any() and b"".join(o.tobytes() for o in outs) == raw.tobytes()
+
+
+def test_reference_known_answers(eng):
+    for dt in (np.uint8, np.uint16, np.uint32, np.float32):                     # test_schunk.cpp:39-75
+        chunks = _roundtrip(eng, dt, np.arange(4096).astype(dt), 256, blocksize=64)
+        assert len(chunks) == 4096 * np.dtype(dt).itemsize // 256
+        assert hip.cbuffer_sizes(chunks[0])[0] == 256
+    _roundtrip(eng, np.uint8, np.arange(50, dtype=np.uint8), 4194304)            # test_channel.cpp:46-55
+    _roundtrip(eng, np.uint8, (np.arange(8192) & 255).astype(np.uint8), 4096, blocksize=128)   # :60-69
+    for v in (255, 0, 199, 12, 13, 14, 25, 90, 100):                             # test_image.cpp / python tests
+        for dt in (np.uint8, np.uint16, np.float32, np.float16):
+            _roundtrip(eng, dt, np.full(64 * 16, v).astype(dt), 768 // np.dtype(dt).itemsize // 64 * 64 * np.dtype(dt).itemsize or 64 * np.dtype(dt).itemsize, blocksize=256)
+
+
+def test_edge_geometries(eng):
+    rng = np.random.default_rng(3)
+    a = (rng.integers(0, 40, 6000, dtype=np.uint64) * 0x0101010101).astype(np.uint64)
+    _roundtrip(eng, np.uint64, a, 16384, blocksize=4096)                         # typesize 8: generic plane path
+    _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 300, 41), 5000, blocksize=256)
+    _roundtrip(eng, np.uint8, synth.natural_channel(np.uint8, 333, 77), 9999, blocksize=1000)
+    _roundtrip(eng, np.uint8, np.arange(20, dtype=np.uint8), 4096)               # < 32 bytes -> memcpyed chunk
+    _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 512, 64), 65536, clevel=0)   # clevel 0 -> memcpyed
+    _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 512, 64), 65536, clevel=5)   # LZ4 acceleration 5
+    _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 512, 256), 262144, blocksize=65536)
+    noisy = rng.integers(0, 65536, 20000, dtype=np.uint16)
+    noisy[3000:9000] = 7
+    for destsize in (40000 + 32, 39000, 36000, 30000, 20100, 200):               # blosc2's running-destsize rule
+        _roundtrip(eng, np.uint16, noisy, 40000, blocksize=4096, destsize=destsize)
+
+
+def test_empty_batch_and_unsupported_requests_fail_loudly(eng):
+    assert eng.compress_device(hip.cparams(2), 0, [], [], 0, [], []).size == 0
+    raw = synth.natural_channel(np.uint16, 256, 64)
+    with pytest.raises(hip.CodecError) as ei:
+        eng.compress_host(hip.cparams(2, compcode=hip.ZSTD), raw, [raw.nbytes], [raw.nbytes + 32])
+    assert ei.value.code == -7
+    with pytest.raises(hip.CodecError):
+        eng.compress_host(hip.cparams(2, filters=(0, 0, 0, 0, 0, hip.BITSHUFFLE)), raw, [raw.nbytes], [raw.nbytes + 32])
+
+
+def test_corrupt_chunks_are_reported_not_crashed(eng):
+    a = synth.natural_channel(np.uint16, 1024, 64)
+    (good,) = eng.compress_host(hip.cparams(2), a, [a.nbytes], [a.nbytes + 32])
+    bad = bytearray(good)
+    struct.pack_into("<i", bad, 32, len(good) + 1000)            # bstart outside the chunk
+    outs, status = eng.decompress_host([bytes(bad), good], check=False)
+    assert status[0] < 0 and status[1] == 0
+    assert outs[1].tobytes() == a.tobytes()
+    bad = bytearray(good)
+    first = struct.unpack_from("<i", good, 32)[0]
+    for k in range(first + 4, first + 40):
+        bad[k] ^= 0x5A                                            # garbage inside an LZ4 stream
+    outs, status = eng.decompress_host([bytes(bad)], check=False)
+    assert status[0] < 0 or outs[0].tobytes() != a.tobytes()
+
+
+def test_blosc2_shim_single_chunk_calls(eng):
+    L = hip.load()
+    cp = hip.Blosc2CParams()
+    cp.compcode, cp.clevel, cp.typesize, cp.nthreads, cp.blocksize, cp.splitmode = 1, 9, 2, 4, 32768, 3
+    cp.filters[5] = 1
+    cctx = L.blosc2_create_cctx(cp)
+    dp = hip.Blosc2DParams()
+    dp.nthreads = 1
+    dctx = L.blosc2_create_dctx(dp)
+    a = synth.tiled_channel(np.float16, 2048, 100)
+    src = a.view(np.uint8).ravel()
+    dst = np.zeros(src.size + 32, np.uint8)
+    r = L.blosc2_compress_ctx(cctx, src.ctypes.data, src.size, dst.ctypes.data, dst.size)
+    ro, want = O.compress(O.cparams(2), src, destsize=src.size + 32)
+    assert r == ro and dst[:r].tobytes() == want
+    out = np.zeros(src.size, np.uint8)
+    assert L.blosc2_decompress_ctx(dctx, dst.ctypes.data, 2**31 - 1, out.ctypes.data, out.size) == src.size
+    assert out.tobytes() == src.tobytes()
+    assert L.blosc2_decompress_ctx(dctx, dst.ctypes.data, 2**31 - 1, out.ctypes.data, out.size - 1) == -6
+    L.blosc2_free_ctx(cctx)
+    L.blosc2_free_ctx(dctx)
+
+
+def test_full_size_config2_device_resident(eng):
+    """BASELINE configs[1]: 4 x 4096^2 float16, 32 chunks of 4 MiB, device-resident batch calls."""
+    chans = [synth.tiled_channel(np.float16, 4096, 4096, c=c) for c in range(4)]
+    host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    n, chunk = host.size, 4 * 1024 * 1024
+    nchunks, stride = n // chunk, chunk + 64
+    d_raw, d_out, d_comp = eng.alloc(n), eng.alloc(n), eng.alloc(nchunks * stride)
+    d_raw.upload(host)
+    raw_off = np.arange(nchunks) * chunk
+    comp_off = np.arange(nchunks) * stride
+    cbytes = eng.compress_device(hip.cparams(2), d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+    comp = d_comp.download()
+    po = O.cparams(2)
+    for i in range(nchunks):
+        r, want = O.compress(po, host[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+        assert cbytes[i] == r and comp[comp_off[i]:comp_off[i] + r].tobytes() == want, i
+    eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_out.ptr, raw_off)
+    assert d_out.download().tobytes() == host.tobytes()
+    # idempotence: a second pass over the same buffers gives the same bytes
+    cbytes2 = eng.compress_device(hip.cparams(2), d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+    assert (cbytes2 == cbytes).all() and d_comp.download().tobytes() == comp.tobytes()
+    for b in (d_raw, d_out, d_comp):
+        b.free()
