@@ -40,14 +40,18 @@ BLOCK = 32768
 
 
 def cpu_baseline(raw_channels, budget_s=12.0):
-    """Oracle compress+decompress of the same chunks on the host cores (bounded sample)."""
+    """Oracle compress+decompress of the same chunks on this GPU's share of the host cores (bounded sample)."""
     from concurrent.futures import ThreadPoolExecutor
     import _oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)                                   # one GPU's share of the box
     O.lib()
     p = O.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK)
-    raw = raw_channels[0].view(np.uint8).ravel()           # one channel = 8 chunks = 32 MiB
-    pieces = [raw[o:o + CHUNK] for o in range(0, raw.size, CHUNK)]
+    pieces = []
+    for ch in raw_channels:                                  # all 4 channels = 32 chunks x 4 MiB
+        raw = ch.view(np.uint8).ravel()
+        pieces += [raw[o:o + CHUNK] for o in range(0, raw.size, CHUNK)]
+    nbytes = sum(x.size for x in pieces)
 
     def one(piece):
         r, c = O.compress(p, piece, destsize=CHUNK + 32)
@@ -61,13 +65,14 @@ def cpu_baseline(raw_channels, budget_s=12.0):
         while True:
             list(ex.map(one, pieces))
             reps += 1
-            if time.perf_counter() - t0 > budget_s or reps >= 200:
+            if time.perf_counter() - t0 > budget_s:
                 break
         dt = time.perf_counter() - t0
-    gbps = reps * 2 * raw.size / dt / 1e9
+    gbps = reps * 2 * nbytes / dt / 1e9
     return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (oracle/ CPU restatement, not c-blosc2): channel 0 = {len(pieces)} chunks x 4 MiB, "
-                      f"compress+decompress, {reps} passes over a {cores}-thread pool, {dt:.1f} s"}
+            "sample": f"oracle (oracle/ CPU restatement, not c-blosc2): the same {len(pieces)} chunks x 4 MiB, "
+                      f"compress+decompress per chunk, {reps} passes over a {cores}-thread pool in {dt:.1f} s "
+                      f"({avail} hardware threads visible)"}
 
 
 def main():

@@ -424,13 +424,19 @@ int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_co
     for (int i = 0; i < nchunks; i++)
         if ((rc = e->hip(hipMemcpyAsync((uint8_t*)e->stage_comp.p + d_comp_off[(size_t)i], hc + comp_off[i], (size_t)cb[(size_t)i], hipMemcpyHostToDevice, e->stream), "chunk H2D"))) return rc;
     // chunks with nbytes == 0 carry no blocks; blocksize must still be positive for the planner
-    rc = cimg_decompress_batch_device(e, nchunks, e->stage_comp.p, d_comp_off.data(), nb.data(), bs.data(), e->stage_raw.p, d_raw_off.data(), status);
-    if (rc) return rc;
+    std::vector<int32_t> st((size_t)nchunks, 0);
+    const int drc = cimg_decompress_batch_device(e, nchunks, e->stage_comp.p, d_comp_off.data(), nb.data(), bs.data(), e->stage_raw.p, d_raw_off.data(), st.data());
+    if (status) memcpy(status, st.data(), sizeof(int32_t) * (size_t)nchunks);
+    if (drc == ERR_FAILURE) return drc;                       // the launch itself failed
+    // chunks that decoded cleanly are still delivered when a neighbour in the batch is damaged
+    const std::string chunk_error = e->err;
     uint8_t* hr = (uint8_t*)h_raw;
     for (int i = 0; i < nchunks; i++)
-        if (nb[(size_t)i] > 0)
+        if (nb[(size_t)i] > 0 && st[(size_t)i] == 0)
             if ((rc = e->hip(hipMemcpyAsync(hr + raw_off[i], (uint8_t*)e->stage_raw.p + d_raw_off[(size_t)i], (size_t)nb[(size_t)i], hipMemcpyDeviceToHost, e->stream), "pixels D2H"))) return rc;
-    return cimg_engine_synchronize(e);
+    if ((rc = cimg_engine_synchronize(e))) return rc;
+    if (drc) e->err = chunk_error;
+    return drc;
 }
 
 }  // extern "C"
