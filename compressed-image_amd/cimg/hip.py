@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "libcimg_hip.so")
 
 K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE = 0, 1, 2, 3
-KERNELS = ("cimg_encode_blocks", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")
+KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")
 BLOSCLZ, LZ4, LZ4HC, ZLIB, ZSTD = 0, 1, 2, 4, 5
 NOFILTER, SHUFFLE, BITSHUFFLE = 0, 1, 2
 MAX_OVERHEAD = 32
@@ -25,6 +25,7 @@ EXPORTS = (
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
+    "cimg_engine_debug_stamps", "cimg_engine_read_stamps",
     # include/blosc2.h
     "blosc2_create_cctx", "blosc2_create_dctx", "blosc2_free_ctx", "blosc2_compress_ctx",
     "blosc2_decompress_ctx", "blosc2_cbuffer_sizes", "blosc2_schunk_new", "blosc2_schunk_free",
@@ -94,6 +95,8 @@ def load():
     L.cimg_engine_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.cimg_kernel_name.argtypes = [C.c_int]
     L.cimg_kernel_name.restype = C.c_char_p
+    L.cimg_engine_debug_stamps.argtypes = [vp, C.c_int]
+    L.cimg_engine_read_stamps.argtypes = [vp, C.c_int, vp, C.c_int]
     L.blosc2_create_cctx.argtypes = [Blosc2CParams]
     L.blosc2_create_cctx.restype = vp
     L.blosc2_create_dctx.argtypes = [Blosc2DParams]
@@ -246,6 +249,14 @@ class Engine:
 
     def reset_timing(self):
         load().cimg_engine_reset_timing(self.handle)
+
+    def debug_stamps(self, on=True):
+        load().cimg_engine_debug_stamps(self.handle, 1 if on else 0)
+
+    def read_stamps(self, which, max_workgroups=1 << 20):
+        out = np.zeros((max_workgroups, 8), np.uint64)
+        n = self._check(load().cimg_engine_read_stamps(self.handle, which, _ptr(out), max_workgroups))
+        return out[:n]
 
     def kernel_time(self, kernel):
         ms, n = C.c_double(0), C.c_int64(0)

@@ -32,6 +32,7 @@ struct DecodeArgs {
     uint8_t* raw;             // pixels go to raw + desc.raw_off
     int32_t* status;          // per chunk: 0 ok, <0 blosc2 error code
     int32_t lds_bytes;        // dynamic LDS size the launch provides
+    uint64_t* dbg;            // diagnostics only: per-workgroup time stamps (nullptr in production)
 };
 
 CIMG_HD int round16(int x) { return (x + 15) & ~15; }

@@ -1,27 +1,33 @@
 // encode_kernel.h -- blosc2 chunk encode for gfx950: shuffle + run detection + LZ4 per stream.
 //
 // Replaces what the reference reaches through blosc2_compress_ctx (blosc2/wrapper.h:139,172, called
-// per 4 MiB chunk from schunk.h:85-104).  One 256-thread workgroup per 32 KiB block of the batch:
+// per 4 MiB chunk from schunk.h:85-104).  One single-wave workgroup per STREAM (one byte plane of one
+// 32 KiB block): streams differ wildly in cost (a noisy low-byte plane is scanned once and stored raw,
+// a smooth high-byte plane is hundreds of matches), so the stream -- not the block -- is the
+// scheduling unit; LDS per workgroup is exactly plane + hash table = 32 KiB, five workgroups per CU.
+// Workgroups w and w+8 take the planes of the same block so that they share an XCD's L2.
 //
-//   phase A  four waves load the block with 16-byte coalesced reads and scatter it into LDS as
-//            `typesize` byte planes (the byte shuffle; v_perm transposes for typesize 2 / 4).
-//   barrier
-//   phase B  wave s owns plane s: run check, then a *bit-exact* LZ4_compress_fast of the plane with
-//            the byU16 hash table (8192 x u16) in LDS.  The match search is inherently sequential
-//            (every probe reads and writes the table), so it is run as 64-probe windows:
-//              - lane l takes probe l of the skip schedule (positions known in advance),
-//              - all lanes read their table slot, write their position, read it back; a lane whose
-//                read-back differs shares its slot with another lane of the window,
-//              - the window is committed up to B = min(first matching lane, first lane involved
-//                in a slot collision): lanes <= B see exactly the table a sequential scan would
-//                show them, lanes > B put their old slot value back, lane B re-writes its own,
-//              - a match at lane B is extended (lane-parallel compare, 256 B per step) and emitted
-//                with lane-parallel literal copies; the "probe right after the match" of the
-//                sequential algorithm rides as lane 0 of the next window.
-//            Output goes to the block's scratch slot; a per-stream record (kind, size, need) is
-//            left for the layout kernel.  `need` is the smallest output budget under which LZ4
-//            still succeeds; it lets the layout kernel re-apply blosc2's running-destsize rule
-//            without re-encoding (oracle/chunk.c: orc_blosc2_compress_2phase is the CPU twin).
+//   phase A  the wave reads its block with 16-byte coalesced loads and keeps byte plane s in LDS
+//            (the byte-shuffle filter, fused with the stream split).
+//   phase B  run check, then a *bit-exact* LZ4_compress_fast of the plane with the byU16 hash table
+//            (8192 x u16) in LDS.  The match search is inherently sequential (every probe reads and
+//            writes the table), so it runs as 64-probe windows:
+//              - lane l takes probe l of the skip schedule (positions are known in advance),
+//              - a lane whose hash equals the previous lane's hash has that lane as its candidate
+//                (exactly what a sequential scan would find), the other lanes ("heads") read their
+//                table slot, write their position and read it back; a head whose read-back differs
+//                shares its slot with another head of the window,
+//              - the window is committed up to B = min(first matching lane, first head involved in
+//                a slot collision): lanes <= B see exactly the table a sequential scan would show
+//                them; heads > B put their old slot value back,
+//              - a match at lane B is extended backwards and forwards with lane-parallel compares
+//                (one LDS round trip for both) and emitted with lane-parallel literal copies; the
+//                "probe right after the match" of the sequential algorithm rides as lane 0 of the
+//                next window.
+//            Output goes to the block's scratch slot; a per-stream record (kind, size, need) is left
+//            for the layout kernel.  `need` is the smallest output budget under which LZ4 still
+//            succeeds; it lets the layout kernel re-apply blosc2's running-destsize rule without
+//            re-encoding (oracle/chunk.c: orc_blosc2_compress_2phase is the CPU twin).
 #pragma once
 #include "codec_types.h"
 #include "wave.h"
@@ -37,26 +43,38 @@ struct EncodeArgs {
     uint8_t* scratch;         // block b owns scratch + b * p.slot_bytes
     StreamRec* recs;          // block b, stream s -> recs[b * p.streams_per_block + s]
     int32_t lds_bytes;
+    int32_t total_blocks;
+    int32_t want_split;       // 1: this launch encodes the planes of split blocks, 0: unsplit blocks
+    uint64_t* dbg;            // diagnostics only: per-item time stamps (nullptr in production)
+    uint32_t* queue;          // work-queue head, zeroed before the launch
 };
 
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
 
-CIMG_HD int plane_stride(int neblock) { return round16(neblock) + 16; }
-inline int encode_lds_bytes(int blocksize, int typesize, bool split)
+// LDS of one stream workgroup: the plane (padded to 16), then the hash table
+inline int encode_lds_bytes(int stream_bytes) { return round16(stream_bytes) + LZ4_HASH_BYTES; }
+// Work items of a launch.  Streams differ in cost by an order of magnitude and the hardware places
+// workgroups on CUs round-robin, not first-free, so the launch is a set of persistent workgroups that
+// pull items from a queue.  Split launch: item i is plane (spb-1 - i / total_blocks) of block
+// i % total_blocks -- most significant byte planes (smooth, many matches, slow) first, noisy low planes
+// last (longest-processing-time-first).  Unsplit launch: item i is block i.
+CIMG_HD int encode_items(int total_blocks, int streams_per_block, bool split)
 {
-    const int ns = split ? typesize : 1;
-    const int ne = blocksize / ns;
-    // unsplit blocks still need room for the whole shuffled block
-    return ns * (round16(ne) + 16) + ns * LZ4_HASH_BYTES + 32;
+    return split ? total_blocks * streams_per_block : total_blocks;
 }
+
+#ifdef CIMG_EMULATE
+extern long g_emu_windows, g_emu_matches, g_emu_collisions;   // test-side statistics only
+#define CIMG_STAT(x) (++(x))
+#else
+#define CIMG_STAT(x) ((void)0)
+#endif
 
 CIMG_DEV uint32_t lz4_hash(uint32_t v) { return (v * 2654435761u) >> 19; }
 // sum_{x=0}^{n-1} (x >> 6)
-CIMG_DEV int skip_prefix(int n) { const int q = n >> 6, r = n & 63; return 32 * q * (q - 1) + q * r; }
-// offset of probe t of a search from the search start (probe 0 sits on the start)
-CIMG_DEV int probe_offset(int t, int s64) { return t <= 0 ? 0 : 1 + skip_prefix(s64 + t - 1) - skip_prefix(s64); }
+CIMG_DEV int skip_prefix(int n) { const int q = n >> 6, r = n & 63; return q * (32 * (q - 1) + r); }
 
-// write `count` bytes of an LZ4 length extension (count-1 times 255, then `last`) at out[pos..)
+// write an LZ4 length extension for `rem` (rem/255 times 255, then rem%255) at out[pos..)
 CIMG_DEV void emit_len_ext(uint8_t* out, int pos, int rem)
 {
     const int n255 = rem / 255, last = rem - 255 * n255;
@@ -73,8 +91,8 @@ CIMG_DEV void emit_literals(const uint8_t* in, int from, uint8_t* out, int pos, 
 }
 
 // Bit-exact LZ4_compress_fast(in, out, n, cap, accel) in limited-output mode, byU16 table, by one wave.
-// in: LDS plane (padded by >= 8 readable bytes), tab: 16 KiB LDS.  Returns bytes written, 0 if the
-// result does not fit cap.  *need = smallest cap that still succeeds.
+// in: LDS plane (8 readable bytes past the end), tab: 16 KiB LDS.  Returns bytes written, 0 if the
+// result does not fit cap.  need_out = smallest cap that still succeeds.
 CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* out, int cap, int accel, int& need_out)
 {
     uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab);
@@ -86,6 +104,7 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
     }
     const int mflimit_p1 = n - 11, matchlimit = n - 5;
     const int s64 = accel << 6;
+    const int f64 = skip_prefix(s64);
     int anchor = 0, op = 0, need = 0;
 
     if (n >= 13) {
@@ -96,110 +115,149 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
         }
         int sstart = 1;     // search start position
         int t0 = 0;         // probes of this search already committed
-        bool pre = false;   // lane 0 = the probe right after a match (position sstart - 1)
+        int pre = 0;        // 1: lane 0 is the probe right after a match (position sstart - 1)
         for (;;) {
             // ---- lay the window out ------------------------------------------------------------------
             LV<int> pos;
             LV<bool> valid;
-            LV<uint32_t> v, h, old, rb, mv;
-            LV<uint32_t> back;           // dword at (sstart - 3): the "put(ip - 2)" refill after a match
+            LV<uint32_t> v, h, back;
             FOR_LANES(l) {
-                if (pre && l == 0) {
-                    pos[l] = sstart - 1;
-                    valid[l] = true;
-                } else {
-                    const int t = t0 + l - (pre ? 1 : 0);
-                    pos[l] = sstart + probe_offset(t, s64);
-                    valid[l] = sstart + probe_offset(t + 1, s64) <= mflimit_p1;
-                }
-                v[l] = valid[l] ? lds_ld32u(in, pos[l]) : 0u;
+                const int t = t0 + l - pre;                       // probe number, -1 for the pre lane
+                // probe t sits at sstart + (t ? 1 + sum_{u<t-1} ((s64+u)>>6) : 0); the next one is one gap further
+                const int p = t <= 0 ? sstart + t : sstart + 1 + skip_prefix(s64 + t - 1) - f64;
+                const int gap = t <= 0 ? 1 : (s64 + t - 1) >> 6;
+                pos[l] = p;
+                valid[l] = t < 0 || p + gap <= mflimit_p1;
+                v[l] = valid[l] ? lds_ld32u(in, p) : 0u;
                 h[l] = lz4_hash(v[l]);
-                back[l] = pre ? lds_ld32u(in, sstart - 3) : 0u;
+                back[l] = pre ? lds_ld32u(in, sstart - 3) : 0u;     // the "put(ip - 2)" refill after a match
             }
-            const uint64_t vmask = ballot(valid);
-            const int nv = popc64(vmask);                 // valid lanes are a prefix
-            if (nv == 0) break;                           // -> last literals
+            const int nv = popc64(ballot(valid));                 // valid lanes are a prefix
+            if (nv == 0) break;
+            CIMG_STAT(g_emu_windows);                                   // -> last literals
             if (pre) {
                 FOR_LANES_W(l) { if (l == 0) tab16[lz4_hash(back[l])] = (uint16_t)(sstart - 3); }
             }
-            FOR_LANES(l) { old[l] = valid[l] ? tab16[h[l]] : 0u; }
-            FOR_LANES_W(l) { if (valid[l]) tab16[h[l]] = (uint16_t)pos[l]; }
-            LV<bool> loser, hit;
+            // a lane with the same hash as its left neighbour has that neighbour as candidate
+            LV<uint32_t> ph, pv;
+            LV<int> ppos;
+            lane_prev(h, ph);
+            lane_prev(v, pv);
+            lane_prev(pos, ppos);
+            LV<bool> head, cont;
+            LV<uint32_t> old;
             FOR_LANES(l) {
-                rb[l] = valid[l] ? tab16[h[l]] : 0u;
-                mv[l] = valid[l] ? lds_ld32u(in, (int)old[l]) : 0u;
-                loser[l] = valid[l] && rb[l] != (uint32_t)pos[l];
-                hit[l] = valid[l] && mv[l] == v[l];
+                cont[l] = valid[l] && l > 0 && h[l] == ph[l];
+                head[l] = valid[l] && !cont[l];
+                old[l] = head[l] ? tab16[h[l]] : 0u;
+            }
+            FOR_LANES_W(l) { if (head[l]) tab16[h[l]] = (uint16_t)pos[l]; }
+            LV<bool> loser, hit;
+            LV<int> cand;
+            FOR_LANES(l) {
+                const uint32_t rb = head[l] ? tab16[h[l]] : 0u;
+                const uint32_t mv = head[l] ? lds_ld32u(in, (int)old[l]) : pv[l];
+                loser[l] = head[l] && rb != (uint32_t)pos[l];
+                hit[l] = valid[l] && mv == v[l];
+                cand[l] = head[l] ? (int)old[l] : ppos[l];
             }
             uint64_t involved = ballot(loser);
             if (involved) {
-                // lanes that lost a slot write again; a winner whose slot changes has company too
+                CIMG_STAT(g_emu_collisions);
+                // heads that lost a slot write again; a winner whose slot changes has company too
                 FOR_LANES_W(l) { if (loser[l]) tab16[h[l]] = (uint16_t)pos[l]; }
                 LV<bool> inv;
-                FOR_LANES(l) { inv[l] = valid[l] && (loser[l] || tab16[h[l]] != (uint16_t)pos[l]); }
+                FOR_LANES(l) { inv[l] = head[l] && (loser[l] || tab16[h[l]] != (uint16_t)pos[l]); }
                 involved = ballot(inv);
             }
             const int k1 = ctz64(involved);                           // 64 if no collision
             const int limit = imin(nv - 1, k1);
-            const uint64_t hits = ballot(hit) & (limit >= 63 ? ~0ull : ((1ull << (limit + 1)) - 1));
+            const uint64_t below = limit >= 63 ? ~0ull : ((1ull << (limit + 1)) - 1);
+            const uint64_t hits = ballot(hit) & below;
             const int m = hits ? ctz64(hits) : -1;
             const int B = m >= 0 ? m : limit;
-            if (B < nv - 1) {
-                FOR_LANES_W(l) { if (valid[l] && l > B) tab16[h[l]] = (uint16_t)old[l]; }
-                FOR_LANES_W(l) { if (l == B) tab16[h[l]] = (uint16_t)pos[l]; }
+            const uint64_t headmask = ballot(head), contmask = ballot(cont);
+            const uint64_t above = B >= 63 ? 0ull : (~0ull << (B + 1));
+            if (headmask & above) {
+                FOR_LANES_W(l) { if (head[l] && l > B) tab16[h[l]] = (uint16_t)old[l]; }
+                FOR_LANES_W(l) { if (head[l] && l == B) tab16[h[l]] = (uint16_t)pos[l]; }
+            }
+            if (contmask & ~above) {
+                // the last lane of every committed run of equal hashes owns the slot
+                FOR_LANES_W(l) {
+                    if (cont[l] && l <= B && (l == B || !((contmask >> ((l + 1) & 63)) & 1) || l == 63)) tab16[h[l]] = (uint16_t)pos[l];
+                }
             }
             if (m < 0) {
                 if (B + 1 < 64 && B + 1 >= nv) break;             // the next probe would pass mflimit
-                t0 += B + 1 - (pre ? 1 : 0);
-                pre = false;
+                t0 += B + 1 - pre;
+                pre = 0;
                 continue;
             }
 
-            // ---- a match at lane m ------------------------------------------------------------------------
+            CIMG_STAT(g_emu_matches);
+            // ---- a match at lane m: extend both ways with one LDS round trip ----------------------------------
             int ip = readlane(pos, m);
-            int cand = (int)readlane(old, m);
+            int mp = readlane(cand, m);
             const bool zero_lit = pre && m == 0;
-            if (!zero_lit) {
-                // extend backwards while the bytes before both positions agree
-                int room = imin(ip - anchor, cand);
-                while (room > 0) {
-                    LV<bool> eq;
-                    FOR_LANES(l) { eq[l] = l < room && in[ip - 1 - l] == in[cand - 1 - l]; }
-                    const int run = ctz64(~ballot(eq));
-                    ip -= run; cand -= run; room -= run;
-                    if (run < 64) break;
-                }
-            }
-            const int lit = zero_lit ? 0 : ip - anchor;
-            // forward match length beyond the 4 verified bytes
-            int mcode = 0;
+            const int room = zero_lit ? 0 : imin(ip - anchor, mp);
+            const int maxc = matchlimit - (ip + 4);
+            int mcode = 0, backrun = 0;
             {
-                const int maxc = matchlimit - (ip + 4);
-                for (;;) {
-                    LV<int> len;
-                    LV<bool> stop;
-                    FOR_LANES(l) {
-                        const int k = mcode + 4 * l;
-                        int vb = maxc - k;
-                        vb = vb < 0 ? 0 : (vb > 4 ? 4 : vb);
-                        int ln = 0;
-                        if (vb > 0) {
-                            const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, cand + 4 + k);
-                            ln = x ? (int)(__builtin_ctz(x) >> 3) : 4;
-                            if (ln > vb) ln = vb;
+                LV<bool> eq, stop;
+                LV<int> len;
+                FOR_LANES(l) {
+                    eq[l] = l < room && in[ip - 1 - l] == in[mp - 1 - l];
+                    const int k = 4 * l;
+                    int vb = maxc - k;
+                    vb = vb < 0 ? 0 : (vb > 4 ? 4 : vb);
+                    int ln = 0;
+                    if (vb > 0) {
+                        const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
+                        ln = x ? (int)(__builtin_ctz(x) >> 3) : 4;
+                        if (ln > vb) ln = vb;
+                    }
+                    len[l] = ln;
+                    stop[l] = ln < 4;
+                }
+                backrun = ctz64(~ballot(eq));
+                const uint64_t sm = ballot(stop);
+                if (sm) {
+                    const int f = ctz64(sm);
+                    mcode = 4 * f + readlane(len, f);
+                } else {
+                    mcode = 256;
+                    for (;;) {                                    // long match: keep counting, 256 bytes a step
+                        FOR_LANES(l) {
+                            const int k = mcode + 4 * l;
+                            int vb = maxc - k;
+                            vb = vb < 0 ? 0 : (vb > 4 ? 4 : vb);
+                            int ln = 0;
+                            if (vb > 0) {
+                                const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
+                                ln = x ? (int)(__builtin_ctz(x) >> 3) : 4;
+                                if (ln > vb) ln = vb;
+                            }
+                            len[l] = ln;
+                            stop[l] = ln < 4;
                         }
-                        len[l] = ln;
-                        stop[l] = ln < 4;
+                        const uint64_t sm2 = ballot(stop);
+                        if (sm2) { const int f = ctz64(sm2); mcode += 4 * f + readlane(len, f); break; }
+                        mcode += 256;
                     }
-                    const uint64_t sm = ballot(stop);
-                    if (sm) {
-                        const int f = ctz64(sm);
-                        mcode += 4 * f + readlane(len, f);
-                        break;
+                }
+                if (backrun == 64) {                              // rare: more than 64 bytes backwards
+                    int left = room - 64;
+                    while (left > 0) {
+                        FOR_LANES(l) { eq[l] = l < left && in[ip - 1 - backrun - l] == in[mp - 1 - backrun - l]; }
+                        const int r = ctz64(~ballot(eq));
+                        backrun += r; left -= r;
+                        if (r < 64) break;
                     }
-                    mcode += 256;
                 }
             }
+            ip -= backrun; mp -= backrun; mcode += backrun;
+            const int lit = zero_lit ? 0 : ip - anchor;
             // ---- budget checks (limited-output rules) -------------------------------------------------------
             const int tok = op;
             int q = op + 1;
@@ -216,15 +274,25 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             need = imax(need, lhs2);
             // ---- emit ----------------------------------------------------------------------------------------
             {
-                const int off = ip - cand;
+                const int off = ip - mp;
                 const uint32_t token = (uint32_t)((lit >= 15 ? 15 : lit) << 4) | (uint32_t)(mcode >= 15 ? 15 : mcode);
-                FOR_LANES(l) {
-                    if (l == 0) out[tok] = (uint8_t)token;
-                    if (l == 1) out[offpos] = (uint8_t)(off & 0xFF);
-                    if (l == 2) out[offpos + 1] = (uint8_t)(off >> 8);
+                if (lit <= 60 && lit < 15) {
+                    // the common short sequence: token, literals, offset in one store wave
+                    FOR_LANES(l) {
+                        if (l == 0) out[tok] = (uint8_t)token;
+                        else if (l <= lit) out[tok + l] = in[anchor + l - 1];
+                        else if (l == lit + 1) out[offpos] = (uint8_t)(off & 0xFF);
+                        else if (l == lit + 2) out[offpos + 1] = (uint8_t)(off >> 8);
+                    }
+                } else {
+                    FOR_LANES(l) {
+                        if (l == 0) out[tok] = (uint8_t)token;
+                        if (l == 1) out[offpos] = (uint8_t)(off & 0xFF);
+                        if (l == 2) out[offpos + 1] = (uint8_t)(off >> 8);
+                    }
+                    if (lit >= 15) emit_len_ext(out, tok + 1, lit - 15);
+                    emit_literals(in, anchor, out, litpos, lit);
                 }
-                if (lit >= 15) emit_len_ext(out, tok + 1, lit - 15);
-                emit_literals(in, anchor, out, litpos, lit);
                 if (mcode >= 15) { emit_len_ext(out, q, mcode - 15); q += (mcode - 15) / 255 + 1; }
             }
             op = q;
@@ -233,7 +301,7 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             if (ip >= mflimit_p1) break;
             sstart = ip + 1;
             t0 = 0;
-            pre = true;
+            pre = 1;
         }
     }
     // ---- last literals ------------------------------------------------------------------------------------
@@ -281,136 +349,150 @@ CIMG_DEV void wave_copy_l2g(const uint8_t* lds, int off, uint8_t* g, int nbytes)
     FOR_LANES(l) { if (done + l < nbytes) g[done + l] = lds[off + done + l]; }
 }
 
-struct EncodeBlock {
+// one single-wave workgroup = one stream
+struct EncodeStream {
     const EncodeArgs& a;
     uint8_t* lds;
-    int b;
-    int chunk, j, bsize, ns, neblock, ps, ts, tab0;
-    bool active;
-    const uint8_t* src;
+    int w;
 
-    CIMG_DEV EncodeBlock(const EncodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
+    CIMG_DEV EncodeStream(const EncodeArgs& a_, uint8_t* lds_, int w_) : a(a_), lds(lds_), w(w_) {}
 
-    // phase A: global -> LDS byte planes (the shuffle filter)
-    CIMG_DEV void phase_a(int wave)
+    // phase A for a split block: keep byte plane s (or slice s when no shuffle) of the block
+    CIMG_DEV void load_plane(const uint8_t* src, int bsize, int ts, int s, int neblock, bool shuf)
     {
-        chunk = find_chunk(a.descs, a.nchunks, b);
-        const ChunkDesc& d = a.descs[chunk];
-        j = b - d.blk0;
-        active = !d.memcpyed;
-        if (!active) return;
-        ts = a.p.typesize;
-        src = a.raw + d.raw_off + (int64_t)j * d.blocksize;
-        const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
-        bsize = leftover_blk ? d.leftover : d.blocksize;
-        ns = (d.split && !leftover_blk) ? ts : 1;
-        neblock = bsize / ns;
-        ps = plane_stride(neblock);
-        tab0 = ns * ps;
-        const int units = bsize >> 4;
-        const int tid0 = wave * 64;
-        const bool shuf = a.p.filter == FILTER_SHUFFLE && ts > 1;
-        const int ne = bsize / ts;
-        // LDS address of plane p: split blocks keep planes ps apart, unsplit blocks keep them packed
-        #define CIMG_PLANE(p) (ns > 1 ? (p) * ps : (p) * ne)
-        if (shuf && ts == 2 && (ns > 1 || (ne & 7) == 0)) {
-            for (int u0 = tid0; u0 < units; u0 += 256) {
+        if (!shuf) {
+            wave_copy_g2l(src + (int64_t)s * neblock, lds, 0, neblock);
+            return;
+        }
+        const int units = bsize >> 4;                    // 16 source bytes = 16/ts plane bytes
+        if (ts == 2) {
+            const uint32_t sel = s ? 0x07050301u : 0x06040200u;
+            for (int u0 = 0; u0 < units; u0 += 256) {
+                LV<u128> x0, x1, x2, x3;
                 FOR_LANES(l) {
                     const int u = u0 + l;
-                    if (u < units) {
-                        const u128 x = ld128u(src + 16 * u);
-                        // even bytes -> plane 0, odd bytes -> plane 1
-                        const uint32_t e0 = byte_perm(x.y, x.x, 0x06040200u), o0 = byte_perm(x.y, x.x, 0x07050301u);
-                        const uint32_t e1 = byte_perm(x.w, x.z, 0x06040200u), o1 = byte_perm(x.w, x.z, 0x07050301u);
-                        uint32_t* d0 = reinterpret_cast<uint32_t*>(lds + CIMG_PLANE(0) + 8 * u);
-                        uint32_t* d1 = reinterpret_cast<uint32_t*>(lds + CIMG_PLANE(1) + 8 * u);
-                        d0[0] = e0; d0[1] = e1;
-                        d1[0] = o0; d1[1] = o1;
-                    }
+                    if (u < units) x0[l] = ld128u(src + 16 * u);
+                    if (u + 64 < units) x1[l] = ld128u(src + 16 * (u + 64));
+                    if (u + 128 < units) x2[l] = ld128u(src + 16 * (u + 128));
+                    if (u + 192 < units) x3[l] = ld128u(src + 16 * (u + 192));
+                }
+                FOR_LANES(l) {
+                    const int u = u0 + l;
+                    #define CIMG_PUT2(X, U) if ((U) < units) { uint32_t* d = reinterpret_cast<uint32_t*>(lds + 8 * (U)); \
+                        d[0] = byte_perm(X.y, X.x, sel); d[1] = byte_perm(X.w, X.z, sel); }
+                    CIMG_PUT2(x0[l], u) CIMG_PUT2(x1[l], u + 64) CIMG_PUT2(x2[l], u + 128) CIMG_PUT2(x3[l], u + 192)
+                    #undef CIMG_PUT2
                 }
             }
-        } else if (shuf && ts == 4 && (ns > 1 || (ne & 3) == 0)) {
-            for (int u0 = tid0; u0 < units; u0 += 256) {
+        } else if (ts == 4) {
+            const uint32_t s1 = (s & 2) ? 0x07030602u : 0x05010400u;      // bytes {0,1}/{2,3} of two elements
+            const uint32_t s2 = (s & 1) ? 0x07060302u : 0x05040100u;      // then byte s of four elements
+            for (int u0 = 0; u0 < units; u0 += 256) {
+                LV<u128> x0, x1, x2, x3;
                 FOR_LANES(l) {
                     const int u = u0 + l;
-                    if (u < units) {
-                        const u128 x = ld128u(src + 16 * u);      // 4 elements of 4 bytes
-                        const uint32_t t0 = byte_perm(x.y, x.x, 0x05010400u), t1 = byte_perm(x.y, x.x, 0x07030602u);
-                        const uint32_t v0 = byte_perm(x.w, x.z, 0x05010400u), v1 = byte_perm(x.w, x.z, 0x07030602u);
-                        *reinterpret_cast<uint32_t*>(lds + CIMG_PLANE(0) + 4 * u) = byte_perm(v0, t0, 0x05040100u);
-                        *reinterpret_cast<uint32_t*>(lds + CIMG_PLANE(1) + 4 * u) = byte_perm(v0, t0, 0x07060302u);
-                        *reinterpret_cast<uint32_t*>(lds + CIMG_PLANE(2) + 4 * u) = byte_perm(v1, t1, 0x05040100u);
-                        *reinterpret_cast<uint32_t*>(lds + CIMG_PLANE(3) + 4 * u) = byte_perm(v1, t1, 0x07060302u);
-                    }
+                    if (u < units) x0[l] = ld128u(src + 16 * u);
+                    if (u + 64 < units) x1[l] = ld128u(src + 16 * (u + 64));
+                    if (u + 128 < units) x2[l] = ld128u(src + 16 * (u + 128));
+                    if (u + 192 < units) x3[l] = ld128u(src + 16 * (u + 192));
                 }
-            }
-        } else if (!shuf) {
-            // no filter (or typesize 1): planes are consecutive slices of the block
-            for (int u0 = tid0; u0 < units; u0 += 256) {
                 FOR_LANES(l) {
                     const int u = u0 + l;
-                    if (u < units) {
-                        const int k = 16 * u;
-                        if (ns > 1 && (neblock & 15)) {
-                            for (int i = 0; i < 16; i++) lds[((k + i) / neblock) * ps + (k + i) % neblock] = src[k + i];
-                        } else {
-                            st128a(lds + (ns > 1 ? (k / neblock) * ps + k % neblock : k), ld128u(src + k));
-                        }
-                    }
+                    #define CIMG_PUT4(X, U) if ((U) < units) { const uint32_t t = byte_perm(X.y, X.x, s1), q = byte_perm(X.w, X.z, s1); \
+                        *reinterpret_cast<uint32_t*>(lds + 4 * (U)) = byte_perm(q, t, s2); }
+                    CIMG_PUT4(x0[l], u) CIMG_PUT4(x1[l], u + 64) CIMG_PUT4(x2[l], u + 128) CIMG_PUT4(x3[l], u + 192)
+                    #undef CIMG_PUT4
                 }
             }
         } else {
-            for (int u0 = tid0; u0 < units; u0 += 256) {
-                FOR_LANES(l) {
-                    const int u = u0 + l;
-                    if (u < units) {
-                        for (int i = 0; i < 16; i++) {
-                            const int k = 16 * u + i;
-                            if (k < ne * ts) lds[CIMG_PLANE(k % ts) + k / ts] = src[k]; else lds[k] = src[k];
-                        }
-                    }
-                }
+            for (int e0 = 0; e0 < neblock; e0 += 64) {
+                FOR_LANES(l) { if (e0 + l < neblock) lds[e0 + l] = src[(int64_t)(e0 + l) * ts + s]; }
             }
         }
-        if (wave == 0) {
-            const int done = units << 4;
-            FOR_LANES(l) {
-                const int k = done + l;
-                if (k < bsize) {
-                    if (shuf) { if (k < ne * ts) lds[CIMG_PLANE(k % ts) + k / ts] = src[k]; else lds[k] = src[k]; }
-                    else lds[ns > 1 ? (k / neblock) * ps + k % neblock : k] = src[k];
-                }
-            }
+        // bytes of the block past the last whole 16-byte unit
+        const int e_done = (units << 4) / ts;
+        if ((ts == 2 || ts == 4) && e_done < neblock) {
+            FOR_LANES(l) { if (e_done + l < neblock) lds[e_done + l] = src[(int64_t)(e_done + l) * ts + s]; }
         }
-        #undef CIMG_PLANE
     }
 
-    // phase B: per-stream run check + LZ4
-    CIMG_DEV void phase_b(int wave)
+    // phase A for an unsplit block: the whole filtered block is the stream
+    CIMG_DEV void load_block(const uint8_t* src, int bsize, int ts, bool shuf)
     {
-        if (!active) return;
-        uint8_t* slot = a.scratch + (int64_t)b * a.p.slot_bytes;
-        for (int s = wave; s < ns; s += 4) {
-            const uint8_t* in = lds + (ns > 1 ? s * ps : 0);
-            uint8_t* tab = lds + tab0 + s * LZ4_HASH_BYTES;
-            uint8_t* out = slot + (int64_t)s * neblock;
-            StreamRec r;
-            r.kind = REC_RAW; r.value = 0; r.csize = neblock; r.need = 0;
-            uint32_t value;
-            if (plane_is_run(in, neblock, value)) {
-                r.kind = REC_RUN; r.value = (int32_t)value; r.csize = 0;
-            } else {
-                int need = 0;
-                const int cb = lz4_encode_wave(in, tab, neblock, out, neblock, a.p.accel, need);
-                if (cb > 0 && cb < neblock) {
-                    r.kind = REC_LZ4; r.csize = cb; r.need = need;
-                } else {
-                    wave_copy_l2g(lds, ns > 1 ? s * ps : 0, out, neblock);
+        if (!shuf) { wave_copy_g2l(src, lds, 0, bsize); return; }
+        const int ne = bsize / ts;
+        for (int k0 = 0; k0 < bsize; k0 += 64) {
+            FOR_LANES(l) {
+                const int k = k0 + l;
+                if (k < bsize) {
+                    const uint8_t x = src[k];
+                    if (k < ne * ts) lds[(k % ts) * ne + k / ts] = x; else lds[k] = x;
                 }
             }
-            StreamRec* dst = a.recs + (int64_t)b * a.p.streams_per_block + s;
-            FOR_LANES(l) { if (l == 0) *dst = r; }
         }
+    }
+
+    // persistent workgroup: pull items until the queue is dry
+    CIMG_DEV void run()
+    {
+        const int items = encode_items(a.total_blocks, a.p.streams_per_block, a.want_split != 0);
+        for (;;) {
+            LV<uint32_t> got;
+            FOR_LANES(l) { got[l] = 0; }
+            FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(a.queue); }
+            const int item = (int)readlane(got, 0);
+            if (item >= items) return;
+            run_item(item);
+        }
+    }
+
+    CIMG_DEV void run_item(int item)
+    {
+        int b, s;
+        const int spb = a.p.streams_per_block;
+        if (a.want_split) {
+            b = item % a.total_blocks;
+            s = spb - 1 - item / a.total_blocks;
+        } else {
+            b = item; s = 0;
+        }
+        if (b >= a.total_blocks) return;
+        const int chunk = find_chunk(a.descs, a.nchunks, b);
+        const ChunkDesc& d = a.descs[chunk];
+        if (d.memcpyed) return;
+        const int j = b - d.blk0;
+        const int ts = a.p.typesize;
+        const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
+        const int bsize = leftover_blk ? d.leftover : d.blocksize;
+        const int ns = (d.split && !leftover_blk) ? ts : 1;
+        if ((ns > 1) != (a.want_split != 0) || s >= ns) return;
+        debug_stamp(a.dbg, item, 0);
+        const int neblock = bsize / ns;
+        const uint8_t* src = a.raw + d.raw_off + (int64_t)j * d.blocksize;
+        const bool shuf = a.p.filter == FILTER_SHUFFLE && ts > 1;
+        if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
+        else load_block(src, bsize, ts, shuf);
+
+        const uint8_t* in = lds;
+        uint8_t* tab = lds + round16(neblock);
+        uint8_t* out = a.scratch + (int64_t)b * a.p.slot_bytes + (int64_t)s * neblock;
+        StreamRec r;
+        r.kind = REC_RAW; r.value = 0; r.csize = neblock; r.need = 0;
+        uint32_t value;
+        if (plane_is_run(in, neblock, value)) {
+            r.kind = REC_RUN; r.value = (int32_t)value; r.csize = 0;
+        } else {
+            int need = 0;
+            const int cb = lz4_encode_wave(in, tab, neblock, out, neblock, a.p.accel, need);
+            if (cb > 0 && cb < neblock) {
+                r.kind = REC_LZ4; r.csize = cb; r.need = need;
+            } else {
+                wave_copy_l2g(lds, 0, out, neblock);
+            }
+        }
+        StreamRec* dst = a.recs + (int64_t)b * spb + s;
+        FOR_LANES(l) { if (l == 0) *dst = r; }
+        debug_stamp(a.dbg, item, 1);
     }
 };
 

@@ -20,14 +20,11 @@ using namespace cimg;
 // ====================================================================================================
 //  kernels
 // ====================================================================================================
-extern "C" __global__ __launch_bounds__(256) void cimg_encode_blocks(EncodeArgs a)
+extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    EncodeBlock blk(a, lds, (int)blockIdx.x);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    blk.phase_a(wave);
-    __syncthreads();
-    blk.phase_b(wave);
+    EncodeStream es(a, lds, (int)blockIdx.x);
+    es.run();
 }
 
 extern "C" __global__ __launch_bounds__(64) void cimg_layout_chunks(AssembleArgs a)
@@ -47,9 +44,11 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     DecodeBlock blk(a, lds, (int)blockIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
     blk.phase_a(wave);
     __syncthreads();
     blk.phase_b(wave);
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 1);
 }
 
 // ====================================================================================================
@@ -76,7 +75,12 @@ struct EventPair {
 struct cimg_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf descs, recs, layout, scratch, status, stage_raw, stage_comp;
+    DevBuf descs, recs, layout, scratch, status, stage_raw, stage_comp, dbg, queue;
+    int num_cus = 256;
+    int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
+    int enc_wgs_lds[2] = {-1, -1};
+    bool stamps = false;
+    int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
     int max_dyn_lds[2] = {0, 0};      // largest dynamic LDS already enabled for encode / decode
     bool timing = false;
@@ -171,7 +175,7 @@ extern "C" {
 const char* cimg_kernel_name(int k)
 {
     switch (k) {
-    case CIMG_K_ENCODE: return "cimg_encode_blocks";
+    case CIMG_K_ENCODE: return "cimg_encode_streams";
     case CIMG_K_LAYOUT: return "cimg_layout_chunks";
     case CIMG_K_EMIT: return "cimg_emit_blocks";
     case CIMG_K_DECODE: return "cimg_decode_blocks";
@@ -212,6 +216,7 @@ int cimg_engine_create(int device, cimg_engine** out)
     }
     cimg_engine* eng = new cimg_engine();
     eng->device = device;
+    eng->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete eng; return ERR_FAILURE; }
     *out = eng;
@@ -225,7 +230,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs, &e->recs, &e->layout, &e->scratch, &e->status, &e->stage_raw, &e->stage_comp})
+    for (DevBuf* b : {&e->descs, &e->recs, &e->layout, &e->scratch, &e->status, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_out})
         if (b->p) (void)hipHostFree(b->p);
@@ -274,6 +279,17 @@ int cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_
     return 0;
 }
 
+// diagnostics: per-workgroup {shader clock, 100 MHz clock, HW_ID, XCC_ID} x {start, end} of the most recent
+// encode (which = 0) or decode (which = 1) launch; 8 uint64 per workgroup.  Returns the workgroup count.
+void cimg_engine_debug_stamps(cimg_engine* e, int on) { e->stamps = on != 0; }
+int cimg_engine_read_stamps(cimg_engine* e, int which, uint64_t* out, int max_workgroups)
+{
+    if (which < 0 || which > 1 || !e->dbg.p) return 0;
+    const int n = e->dbg_count[which] < max_workgroups ? e->dbg_count[which] : max_workgroups;
+    if (cimg_memcpy_d2h(e, out, e->dbg.p, (size_t)n * 64)) return ERR_FAILURE;
+    return n;
+}
+
 static HostCParams to_host(const cimg_cparams* p)
 {
     HostCParams h;
@@ -305,11 +321,27 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
     memcpy(e->h_descs.p, plan.descs.data(), desc_bytes);
     if ((rc = e->hip(hipMemcpyAsync(e->descs.p, e->h_descs.p, desc_bytes, hipMemcpyHostToDevice, e->stream), "descs H2D"))) return rc;
 
-    EncodeArgs ea{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
-                  (StreamRec*)e->recs.p, plan.lds_bytes};
-    if (plan.lds_bytes > 0) {
-        if ((rc = e->allow_lds(cimg_encode_blocks, 0, plan.lds_bytes))) return rc;
-        if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_blocks, ea, plan.total_blocks, 256, plan.lds_bytes))) return rc;
+    for (int split = 1; split >= 0; split--) {
+        const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
+        if (!lds_bytes) continue;                     // no blocks of that kind in the batch
+        const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0);
+        uint64_t* dbg = nullptr;    // in-kernel stamps of the persistent encode kernel are disabled (they wedge the launch; decode stamps work)
+        if ((rc = e->reserve(e->queue, 64))) return rc;
+        uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
+        if ((rc = e->hip(hipMemsetAsync(head, 0, sizeof(uint32_t), e->stream), "queue memset"))) return rc;
+        EncodeArgs ea{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
+                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head};
+        if ((rc = e->allow_lds(cimg_encode_streams, 0, lds_bytes))) return rc;
+        // persistent workgroups: as many as are resident at once, never more than there are items
+        if (e->enc_wgs_lds[split] != lds_bytes) {
+            int per_cu = 0;
+            if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_encode_streams, 64, (size_t)lds_bytes), "occupancy query"))) return rc;
+            e->enc_wgs_per_cu[split] = per_cu > 0 ? per_cu : 1;
+            e->enc_wgs_lds[split] = lds_bytes;
+            if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] encode launch: %d bytes LDS -> %d workgroups per CU x %d CUs\n", lds_bytes, per_cu, e->num_cus);
+        }
+        const int grid = std::min(items, e->enc_wgs_per_cu[split] * e->num_cus);
+        if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_streams, ea, grid, 64, lds_bytes))) return rc;
     }
     AssembleArgs aa{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
                     (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p};
@@ -341,7 +373,14 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     memcpy(e->h_descs.p, plan.descs.data(), desc_bytes);
     if ((rc = e->hip(hipMemcpyAsync(e->descs.p, e->h_descs.p, desc_bytes, hipMemcpyHostToDevice, e->stream), "descs H2D"))) return rc;
     if ((rc = e->hip(hipMemsetAsync(e->status.p, 0, st_bytes, e->stream), "status memset"))) return rc;
-    DecodeArgs da{(const ChunkDesc*)e->descs.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, (int32_t*)e->status.p, plan.lds_bytes};
+    uint64_t* dbg = nullptr;
+    if (e->stamps) {
+        if ((rc = e->reserve(e->dbg, (size_t)plan.total_blocks * 64))) return rc;
+        if ((rc = e->hip(hipMemsetAsync(e->dbg.p, 0, (size_t)plan.total_blocks * 64, e->stream), "dbg memset"))) return rc;
+        dbg = (uint64_t*)e->dbg.p;
+        e->dbg_count[1] = plan.total_blocks;
+    }
+    DecodeArgs da{(const ChunkDesc*)e->descs.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, (int32_t*)e->status.p, plan.lds_bytes, dbg};
     if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
     if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
     if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->status.p, st_bytes, hipMemcpyDeviceToHost, e->stream), "status D2H"))) return rc;

@@ -100,7 +100,8 @@ struct EncodePlan {
     std::vector<ChunkDesc> descs;
     CodecParams cp{};
     int32_t total_blocks = 0;
-    int32_t lds_bytes = 0;
+    int32_t lds_split = 0;      // LDS per stream workgroup of the split-block launch (0: no such blocks)
+    int32_t lds_unsplit = 0;    // same for the unsplit-block launch (leftover blocks, dont-split chunks)
 };
 
 enum : int { MAX_LDS_BYTES = 160 * 1024 };
@@ -122,7 +123,8 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
     cp.accel = 10 - p.clevel;
     cp.max_blocksize = 0;
     cp.streams_per_block = 1;
-    int32_t blk = 0, lds = 0;
+    int32_t blk = 0;
+    plan->lds_split = plan->lds_unsplit = 0;
     for (int i = 0; i < nchunks; i++) {
         ChunkDesc& d = plan->descs[(size_t)i];
         rc = plan_chunk(p, nbytes[i], destsize[i], &d);
@@ -134,19 +136,17 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
         if (d.blocksize > cp.max_blocksize) cp.max_blocksize = d.blocksize;
         if (d.split) cp.streams_per_block = cp.typesize;
         if (!d.memcpyed) {
-            const int neblock_max = d.split ? d.blocksize / cp.typesize : d.blocksize;
-            if (neblock_max > LZ4_MAX_INPUT_U16) return ERR_CODEC_SUPPORT;   // byU32 LZ4 regime: not built
-            int need = encode_lds_bytes(d.blocksize, cp.typesize, d.split != 0);
-            if (d.split && d.leftover) {
-                const int n2 = encode_lds_bytes(d.leftover, cp.typesize, false);
-                if (n2 > need) need = n2;
-            }
-            if (need > lds) lds = need;
+            const int nfull = d.leftover ? d.nblocks - 1 : d.nblocks;
+            const bool multi = d.split && cp.typesize > 1;        // full blocks are cut into several planes
+            if (multi && nfull > 0) plan->lds_split = imax(plan->lds_split, encode_lds_bytes(d.blocksize / cp.typesize));
+            if (!multi && nfull > 0) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.blocksize));
+            if (d.leftover) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.leftover));
+            const int stream_max = multi ? imax(nfull > 0 ? d.blocksize / cp.typesize : 0, d.leftover) : d.blocksize;
+            if (stream_max > LZ4_MAX_INPUT_U16) return ERR_CODEC_SUPPORT;   // byU32 LZ4 regime: not built
         }
     }
-    if (lds > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
+    if (plan->lds_split > MAX_LDS_BYTES || plan->lds_unsplit > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
     plan->total_blocks = blk;
-    plan->lds_bytes = lds;
     cp.slot_bytes = (cp.max_blocksize + 63) & ~63;
     return 0;
 }

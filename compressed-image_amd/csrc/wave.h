@@ -67,8 +67,15 @@ inline void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
     total = run;
 }
 inline int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
-inline void wave_sync_lds() {}
-inline void mem_fence_block() {}
+inline void debug_stamp(uint64_t*, int, int) {}
+inline uint32_t queue_pop(uint32_t* head) { return (*head)++; }
+// value held by lane l-1 (lane 0 keeps its own)
+template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
+{
+    T keep = x.v[0];
+    for (int l = 0; l < 64; ++l) { const T cur = x.v[l]; out.v[l] = keep; keep = cur; }
+    out.v[0] = x.v[0];
+}
 
 }  // namespace cimg
 
@@ -120,6 +127,29 @@ CIMG_DEV int wave_max(const LV<int>& x)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int n = __shfl_xor(v, d); v = n > v ? n : v; }
     return __builtin_amdgcn_readfirstlane(v);
+}
+// one returning device-scope atomic on the queue head (MI355X_MICROARCH.md: 'dequeue', ~0.3-1.1 us)
+CIMG_DEV uint32_t queue_pop(uint32_t* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// diagnostic builds only (dbg != nullptr): slot[4*w + which] = {shader clock, 100 MHz wall clock | hw id}
+CIMG_DEV void debug_stamp(uint64_t* dbg, int w, int which)
+{
+    if (dbg == nullptr) return;
+    const uint64_t t = __builtin_amdgcn_s_memtime();
+    const uint64_t r = __builtin_amdgcn_s_memrealtime();
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));
+    if (__lane_id() == 0) {
+        dbg[8 * (size_t)w + 4 * which + 0] = t;
+        dbg[8 * (size_t)w + 4 * which + 1] = r;
+        dbg[8 * (size_t)w + 4 * which + 2] = hw;
+        dbg[8 * (size_t)w + 4 * which + 3] = xcc;
+    }
+}
+// value held by lane l-1 (lane 0 keeps its own)
+template <class T> CIMG_DEV void lane_prev(const LV<T>& x, LV<T>& out)
+{
+    static_assert(sizeof(T) == 4, "lane_prev moves one dword");
+    out.v = (T)__shfl_up((int)x.v, 1);
 }
 
 }  // namespace cimg

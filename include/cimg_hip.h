@@ -91,6 +91,12 @@ void cimg_engine_reset_timing(cimg_engine* e);
 int  cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_t* launches);
 const char* cimg_kernel_name(int kernel);
 
+/* ---- diagnostics: per-workgroup clock stamps of the most recent encode (0) / decode (1) launch ------
+ * 8 uint64 per workgroup: {shader clock, 100 MHz clock, HW_ID, XCC_ID} at start, then at end.  Off by
+ * default; when on, the NEXT launches stamp (the dbg pointer is null otherwise and the kernels skip it). */
+void cimg_engine_debug_stamps(cimg_engine* e, int on);
+int  cimg_engine_read_stamps(cimg_engine* e, int which, uint64_t* out, int max_workgroups);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,12 +9,13 @@
 #include <cstring>
 #include <vector>
 
-namespace cimg { int g_emu_write_order = 0; }
+namespace cimg { int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
 
 extern "C" {
 
 void emu_set_write_order(int o) { g_emu_write_order = o; }
+void emu_stats(long* out, int reset) { out[0] = g_emu_windows; out[1] = g_emu_matches; out[2] = g_emu_collisions; if (reset) g_emu_windows = g_emu_matches = g_emu_collisions = 0; }
 
 struct EmuCParams {
     int32_t typesize, clevel, blocksize, compcode, splitmode;
@@ -40,13 +41,17 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     std::vector<uint8_t> scratch((size_t)plan.total_blocks * plan.cp.slot_bytes + 64, 0xEE);
     std::vector<StreamRec> recs((size_t)plan.total_blocks * plan.cp.streams_per_block);
     std::vector<ChunkLayout> layout((size_t)nchunks);
-    std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
-    EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), plan.lds_bytes};
-    for (int b = 0; b < plan.total_blocks; b++) {
-        memset(lds.data(), 0xCD, lds.size());
-        EncodeBlock blk(ea, lds.data(), b);
-        for (int w = 0; w < 4; w++) blk.phase_a(w);
-        for (int w = 0; w < 4; w++) blk.phase_b(w);
+    for (int split = 1; split >= 0; split--) {
+        const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
+        if (!lds_bytes) continue;
+        std::vector<uint8_t> lds((size_t)lds_bytes + 64);
+        uint32_t queue = 0;
+        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue};
+        for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
+            memset(lds.data(), 0xCD, lds.size());
+            EncodeStream es(ea, lds.data(), w);
+            es.run();
+        }
     }
     AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data()};
     for (int c = 0; c < nchunks; c++) { LayoutChunk lc(aa, c); lc.run(); }
@@ -63,7 +68,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     if (rc < 0) return rc;
     memset(status, 0, sizeof(int32_t) * (size_t)nchunks);
     std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
-    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes};
+    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr};
     for (int b = 0; b < plan.total_blocks; b++) {
         memset(lds.data(), 0xCD, lds.size());
         DecodeBlock blk(da, lds.data(), b);
@@ -82,7 +87,7 @@ int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, 
     std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
     memcpy(lds.data(), src, (size_t)n);
     int nd = 0;
-    const int r = lz4_encode_wave(lds.data(), lds.data() + round16(n) + 32, n, dst, cap, accel, nd);
+    const int r = lz4_encode_wave(lds.data(), lds.data() + round16(n), n, dst, cap, accel, nd);
     if (need) *need = nd;
     return r;
 }
