@@ -1,0 +1,74 @@
+"""N > 1 path on CPU: two gloo ranks shard the chunks of an image, each runs the codec on its own items
+(the oracle stands in for the engine here -- there is no GPU in this container), and the tiny
+exchanges of cimg/shard.py reproduce the single-process result.  No data-path collective exists.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cimg import shard, synth
+
+
+def test_partition_covers_every_item_once():
+    for n, world, per in [(32, 8, 8), (32, 2, 8), (256, 8, 8), (7, 3, 2), (5, 8, 1), (3, 4, 8)]:
+        seen = np.concatenate([shard.partition(n, world, r, per) for r in range(world)])
+        assert sorted(seen.tolist()) == list(range(n)), (n, world, per)
+    assert shard.partition(32, 4, 3, 8).tolist() == list(range(24, 32))           # config 2 on 4 GPUs: channel 3 -> rank 3
+    assert shard.partition(32, 8, 3, 8).tolist() == [3, 11, 19, 27]                # config 2 on 8 GPUs: 4 channels < 8 ranks -> chunk-granular, 4 chunks each
+    assert shard.partition(2048, 8, 1, 8).tolist()[:9] == list(range(8, 16)) + [72]  # config 4: 256 channels round-robin
+    with pytest.raises(ValueError):
+        shard.partition(4, 2, 2)
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    import _oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        chans = [synth.tiled_channel(np.uint16, 512, 256, c=c) for c in range(3)]       # 3 channels x 4 chunks of 64 KiB
+        raw = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+        chunk = 65536
+        n = raw.size // chunk
+        mine = shard.partition(n, world, rank, items_per_group=4)
+        p = O.cparams(2)
+        sizes, digests = [], []
+        for i in mine:
+            r, c = O.compress(p, raw[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+            back = O.decompress(c)[1]
+            assert back.tobytes() == raw[i * chunk:(i + 1) * chunk].tobytes()
+            sizes.append(r)
+        full = shard.gather_sizes(dist, mine, sizes, n)
+        t = shard.max_over_ranks(dist, 1.0 + rank)
+        out.put((rank, mine.tolist(), full.tolist(), t))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_reproduce_single_process_sizes():
+    import torch.multiprocessing as mp
+    import _oracle as O
+    O.lib()                                    # build before forking
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    chans = [synth.tiled_channel(np.uint16, 512, 256, c=c) for c in range(3)]
+    raw = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    want = [O.compress(O.cparams(2), raw[i * 65536:(i + 1) * 65536], destsize=65536 + 32)[0] for i in range(12)]
+    assert res[0][1] == [0, 1, 2, 3, 8, 9, 10, 11] and res[1][1] == [4, 5, 6, 7]      # channels 0,2 / channel 1
+    for rank, mine, full, t in res:
+        assert full == want
+        assert t == 2.0                                                                 # max over ranks
