@@ -25,7 +25,7 @@ EXPORTS = (
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
-    "cimg_engine_debug_stamps", "cimg_engine_read_stamps",
+    "cimg_engine_debug_stamps", "cimg_engine_read_stamps", "cimg_shared_engine", "cimg_context_cparams",
     # include/blosc2.h
     "blosc2_create_cctx", "blosc2_create_dctx", "blosc2_free_ctx", "blosc2_compress_ctx",
     "blosc2_decompress_ctx", "blosc2_cbuffer_sizes", "blosc2_schunk_new", "blosc2_schunk_free",

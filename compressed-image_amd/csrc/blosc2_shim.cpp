@@ -42,6 +42,16 @@ int32_t rd32(const uint8_t* p) { int32_t v; memcpy(&v, p, 4); return v; }
 
 extern "C" {
 
+cimg_engine* cimg_shared_engine(void) { return shared_engine(); }
+
+int cimg_context_cparams(const blosc2_context_s* context, cimg_cparams* out)
+{
+    if (!context || !out) return BLOSC2_ERROR_NULL_POINTER;
+    if (!context->compress) return BLOSC2_ERROR_INVALID_PARAM;
+    *out = context->cp;
+    return 0;
+}
+
 blosc2_context* blosc2_create_cctx(blosc2_cparams cparams)
 {
     blosc2_context* c = new (std::nothrow) blosc2_context_s();

@@ -1,0 +1,240 @@
+// blosc2/wrapper.h -- host-side seam onto the codec.  Same names and error behaviour as the reference's
+// compressed/blosc2/wrapper.h (codec mapping :74-119, compress :134-223, decompress :236-277,
+// context factories :313-413, size helpers :416-468), served by libcimg_hip.so through
+// include/blosc2.h, plus the *batched* helpers the re-shaped chunk loops use (include/cimg_hip.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "blosc2.h"
+#include "cimg_hip.h"
+
+#include "../macros.h"
+#include "../enums.h"
+#include "../detail/text.h"
+
+namespace NAMESPACE_COMPRESSED_IMAGE
+{
+	namespace blosc2
+	{
+		inline std::string map_error_code(int rc) { return std::string(print_error(rc)); }   // reference blosc2/util.h:16-19
+
+		template <typename S> struct deleter;
+		template <> struct deleter<blosc2_schunk> { void operator()(blosc2_schunk* s) const { blosc2_schunk_free(s); } };
+		template <> struct deleter<blosc2_context> { void operator()(blosc2_context* c) const { blosc2_free_ctx(c); } };
+
+		using schunk_ptr = std::unique_ptr<blosc2_schunk, deleter<blosc2_schunk>>;
+		using schunk_raw_ptr = blosc2_schunk*;
+		using chunk_raw_ptr = void*;
+		using context_ptr = std::unique_ptr<blosc2_context, deleter<blosc2_context>>;
+		using context_raw_ptr = blosc2_context*;
+
+		inline uint8_t codec_to_blosc2(enums::codec c)
+		{
+			switch (c)
+			{
+			case enums::codec::lz4: return BLOSC_LZ4;
+			case enums::codec::lz4hc: return BLOSC_LZ4HC;
+			case enums::codec::zstd: return BLOSC_ZSTD;
+			default: return BLOSC_BLOSCLZ;
+			}
+		}
+		inline enums::codec blosc2_to_codec(uint8_t c)
+		{
+			switch (c)
+			{
+			case BLOSC_LZ4: return enums::codec::lz4;
+			case BLOSC_LZ4HC: return enums::codec::lz4hc;
+			case BLOSC_ZSTD: return enums::codec::zstd;
+			default: return enums::codec::blosclz;
+			}
+		}
+
+		// ---- single chunk (one blosc2_*_ctx call, host pointers) ----------------------------------------------
+		template <typename T>
+		size_t compress(context_raw_ptr context, std::span<const T> data, std::span<std::byte> chunk)
+		{
+			const int cbytes = blosc2_compress_ctx(context, data.data(), static_cast<int32_t>(data.size() * sizeof(T)),
+				chunk.data(), static_cast<int32_t>(chunk.size()));
+			if (cbytes < 0)
+				throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", cbytes));
+			return static_cast<size_t>(cbytes);
+		}
+		template <typename T> size_t compress(context_raw_ptr context, std::span<T> data, std::span<std::byte> chunk) requires(!std::is_const_v<T>)
+		{
+			return compress<T>(context, std::span<const T>(data.data(), data.size()), chunk);
+		}
+		template <typename T> size_t compress(context_ptr& context, std::span<T> data, std::span<std::byte> chunk) { return compress<std::remove_const_t<T>>(context.get(), std::span<const std::remove_const_t<T>>(data.data(), data.size()), chunk); }
+
+		template <typename T>
+		size_t decompress(context_raw_ptr context, std::span<T> buffer, std::span<const std::byte> chunk)
+		{
+			if (buffer.size() * sizeof(T) > static_cast<size_t>(std::numeric_limits<int32_t>::max()))
+				throw std::out_of_range(detail::text("Blosc2 chunk size may not exceed numeric limit of int32_t, got ", buffer.size() * sizeof(T), " which would exceed that"));
+			const int n = blosc2_decompress_ctx(context, chunk.data(), std::numeric_limits<int32_t>::max(), buffer.data(),
+				static_cast<int32_t>(buffer.size() * sizeof(T)));
+			if (n < 0)
+				throw std::runtime_error(detail::text("Error code ", n, " while decompressing blosc2 chunk"));
+			return static_cast<size_t>(n);
+		}
+		template <typename T> size_t decompress(context_ptr& context, std::span<T> buffer, std::span<const std::byte> chunk) { return decompress(context.get(), buffer, chunk); }
+
+		inline size_t append_chunk(schunk_ptr& schunk, std::span<std::byte> chunk)
+		{
+			const auto n = blosc2_schunk_append_chunk(schunk.get(), reinterpret_cast<uint8_t*>(chunk.data()), true);
+			if (n < 0)
+				throw std::runtime_error(detail::text("Unable to append chunk into super-chunk with the following blosc2 error code ", n));
+			return static_cast<size_t>(n);
+		}
+
+		inline schunk_ptr create_default_schunk()
+		{
+			auto cparams = BLOSC2_CPARAMS_DEFAULTS;
+			auto dparams = BLOSC2_DPARAMS_DEFAULTS;
+			blosc2_storage storage = BLOSC2_STORAGE_DEFAULTS;
+			storage.cparams = &cparams;
+			storage.dparams = &dparams;
+			return schunk_ptr(blosc2_schunk_new(&storage));
+		}
+
+		// ---- contexts -----------------------------------------------------------------------------------------
+		template <typename T>
+		blosc2_cparams create_blosc2_cparams(size_t nthreads, enums::codec codec, uint8_t compression_level, size_t block_size)
+		{
+			if (nthreads > static_cast<size_t>(std::numeric_limits<int16_t>::max()))
+				throw std::out_of_range(detail::text("Number of threads may not exceed ", std::numeric_limits<int16_t>::max(), ", got ", nthreads));
+			blosc2_cparams p = BLOSC2_CPARAMS_DEFAULTS;
+			p.blocksize = static_cast<int32_t>(block_size);
+			p.typesize = sizeof(T);
+			p.splitmode = BLOSC_AUTO_SPLIT;
+			p.clevel = compression_level;
+			p.nthreads = static_cast<int16_t>(nthreads == 0 ? 1 : nthreads);    // accepted, ignored: the parallelism is the GPU's
+			p.compcode = codec_to_blosc2(codec);
+			return p;
+		}
+		template <typename T>
+		context_ptr create_compression_context(size_t nthreads, enums::codec codec, uint8_t compression_level, size_t block_size)
+		{
+			return context_ptr(blosc2_create_cctx(create_blosc2_cparams<T>(nthreads, codec, compression_level, block_size)));
+		}
+		template <typename T>
+		context_ptr create_compression_context(schunk_ptr& schunk, size_t nthreads, enums::codec codec, uint8_t compression_level, size_t block_size)
+		{
+			auto p = create_blosc2_cparams<T>(nthreads, codec, compression_level, block_size);
+			p.schunk = schunk.get();
+			return context_ptr(blosc2_create_cctx(p));
+		}
+		inline context_ptr create_decompression_context(size_t nthreads)
+		{
+			if (nthreads > static_cast<size_t>(std::numeric_limits<int16_t>::max()))
+				throw std::out_of_range(detail::text("Number of threads may not exceed ", std::numeric_limits<int16_t>::max(), ", got ", nthreads));
+			auto d = BLOSC2_DPARAMS_DEFAULTS;
+			d.nthreads = 1;
+			return context_ptr(blosc2_create_dctx(d));
+		}
+		inline context_ptr create_decompression_context(schunk_ptr& schunk, size_t nthreads)
+		{
+			auto ctx = create_decompression_context(nthreads);
+			(void)schunk;
+			return ctx;
+		}
+
+		// ---- sizes -----------------------------------------------------------------------------------------------
+		template <size_t ChunkSize> constexpr size_t min_compressed_size() { return ChunkSize + BLOSC2_MAX_OVERHEAD; }
+		inline constexpr size_t min_compressed_size(size_t chunk_size) { return chunk_size + BLOSC2_MAX_OVERHEAD; }
+		template <size_t ChunkSize> constexpr size_t min_decompressed_size() { return ChunkSize; }
+		inline constexpr size_t min_decompressed_size(size_t chunk_size) { return chunk_size; }
+
+		inline size_t chunk_num_bytes(const std::byte* chunk)
+		{
+			int32_t nbytes{}, cbytes{}, blocksize{};
+			const int rc = blosc2_cbuffer_sizes(chunk, &nbytes, &cbytes, &blocksize);
+			if (rc < 0)
+				throw std::runtime_error(detail::text("Unable to find buffer sizes due to blosc2 error: ", map_error_code(rc)));
+			return static_cast<size_t>(nbytes);
+		}
+		template <typename T> size_t chunk_num_elements(const std::vector<std::byte>& chunk) { return chunk_num_bytes(chunk.data()) / sizeof(T); }
+
+		// ---- batches: what replaces the reference's serial chunk loops --------------------------------------------
+		namespace batch
+		{
+			inline cimg_engine* engine()
+			{
+				cimg_engine* e = cimg_shared_engine();
+				if (!e)
+					throw std::runtime_error(detail::text("compressed-image MI355X engine unavailable: ", cimg_last_error(nullptr)));
+				return e;
+			}
+
+			struct piece { const std::byte* data; size_t nbytes; };          // one chunk's pixels (host memory)
+
+			// Compress many chunks in one engine call.  Every chunk gets destsize = nominal chunk size +
+			// BLOSC2_MAX_OVERHEAD, as the reference passes it (schunk.h:73, :200, :225).
+			inline std::vector<std::vector<std::byte>> compress(context_raw_ptr cctx, const std::vector<piece>& pieces, size_t nominal_chunk_bytes)
+			{
+				std::vector<std::vector<std::byte>> out(pieces.size());
+				if (pieces.empty()) return out;
+				cimg_cparams cp;
+				int rc = cimg_context_cparams(cctx, &cp);
+				if (rc < 0) throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc));
+				const size_t n = pieces.size();
+				const size_t stride = (min_compressed_size(nominal_chunk_bytes) + 63) & ~size_t{63};
+				std::vector<int64_t> raw_off(n), comp_off(n);
+				std::vector<int32_t> nbytes(n), destsize(n), cbytes(n);
+				const std::byte* base = pieces[0].data;
+				for (const auto& p : pieces) if (p.data < base) base = p.data;
+				for (size_t i = 0; i < n; ++i)
+				{
+					if (pieces[i].nbytes > static_cast<size_t>(BLOSC2_MAX_BUFFERSIZE))
+						throw std::out_of_range(detail::text("Blosc2 chunk size may not exceed numeric limit of int32_t, got ", pieces[i].nbytes));
+					raw_off[i] = pieces[i].data - base;
+					nbytes[i] = static_cast<int32_t>(pieces[i].nbytes);
+					comp_off[i] = static_cast<int64_t>(i * stride);
+					destsize[i] = static_cast<int32_t>(min_compressed_size(nominal_chunk_bytes));
+				}
+				std::vector<std::byte> staging(n * stride);
+				rc = cimg_compress_batch_host(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(),
+					staging.data(), comp_off.data(), destsize.data(), cbytes.data());
+				if (rc < 0)
+					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
+				for (size_t i = 0; i < n; ++i)
+				{
+					if (cbytes[i] <= 0)
+						throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", cbytes[i]));
+					out[i].assign(staging.begin() + comp_off[i], staging.begin() + comp_off[i] + cbytes[i]);
+				}
+				return out;
+			}
+
+			struct target { const std::byte* chunk; std::byte* out; size_t capacity; };   // one chunk -> its pixels
+
+			inline void decompress(const std::vector<target>& items)
+			{
+				if (items.empty()) return;
+				const size_t n = items.size();
+				const std::byte* cbase = items[0].chunk;
+				std::byte* rbase = items[0].out;
+				for (const auto& t : items) { if (t.chunk < cbase) cbase = t.chunk; if (t.out < rbase) rbase = t.out; }
+				std::vector<int64_t> comp_off(n), raw_off(n);
+				std::vector<int32_t> cap(n), status(n);
+				for (size_t i = 0; i < n; ++i)
+				{
+					if (items[i].capacity > static_cast<size_t>(std::numeric_limits<int32_t>::max()))
+						throw std::out_of_range(detail::text("Blosc2 chunk size may not exceed numeric limit of int32_t, got ", items[i].capacity, " which would exceed that"));
+					comp_off[i] = items[i].chunk - cbase;
+					raw_off[i] = items[i].out - rbase;
+					cap[i] = static_cast<int32_t>(items[i].capacity);
+				}
+				const int rc = cimg_decompress_batch_host(engine(), static_cast<int32_t>(n), cbase, comp_off.data(), rbase, raw_off.data(), cap.data(), status.data());
+				if (rc < 0)
+					throw std::runtime_error(detail::text("Error code ", rc, " while decompressing blosc2 chunk"));
+			}
+		}
+	}
+}

@@ -77,6 +77,15 @@ int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks,
                                void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity,
                                int32_t* status);
 
+/* ---- glue between the blosc2 shim and the batched calls ----------------------------------------------
+ * The single-chunk blosc2_*_ctx calls run on one process-wide engine (device $CIMG_DEVICE, else the
+ * current HIP device); cimg_shared_engine() hands it out so that host code holding blosc2 contexts
+ * (the re-shaped schunk / image loops) can batch on the same stream.  NULL + cimg_last_error(NULL) on
+ * failure.  cimg_context_cparams() copies the codec parameters a compression context was created with. */
+struct blosc2_context_s;
+cimg_engine* cimg_shared_engine(void);
+int cimg_context_cparams(const struct blosc2_context_s* context, cimg_cparams* out);
+
 /* ---- device memory without HIP headers ------------------------------------------------------------ */
 void* cimg_device_malloc(cimg_engine* e, size_t bytes);
 void  cimg_device_free(cimg_engine* e, void* p);

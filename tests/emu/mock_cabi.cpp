@@ -1,0 +1,71 @@
+// tests/emu/mock_cabi.cpp -- TEST INFRASTRUCTURE: the cimg_* engine entry points of include/cimg_hip.h
+// implemented on the host lane emulator (tests/emu/emu.cpp), so that the host-side C++ mirror
+// (compressed-image_amd/include/compressed) and the pybind11 module can be exercised in a container
+// without a GPU.  Linked together with csrc/blosc2_shim.cpp into tests/emu/libcimg_hip_mock.so, which
+// only tests load; the product links libcimg_hip.so and has no such path.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/cimg_hip.h"
+
+extern "C" {
+struct EmuCParams { int32_t typesize, clevel, blocksize, compcode, splitmode; uint8_t filters[6], filters_meta[6]; };
+int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, const int64_t* raw_off, const int32_t* nbytes,
+                       uint8_t* comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes);
+int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_off, const int32_t* nbytes, const int32_t* blocksize,
+                         uint8_t* raw, const int64_t* raw_off, int32_t* status);
+}
+
+struct cimg_engine { std::string err; };
+static std::string g_err;
+
+extern "C" {
+
+void cimg_cparams_init(cimg_cparams* p, int32_t typesize)
+{
+    memset(p, 0, sizeof(*p));
+    p->typesize = typesize; p->clevel = 9; p->blocksize = 32768; p->compcode = 1; p->splitmode = 3; p->filters[5] = 1;
+}
+int cimg_engine_create(int, cimg_engine** out) { *out = new cimg_engine(); return 0; }
+void cimg_engine_destroy(cimg_engine* e) { delete e; }
+const char* cimg_last_error(const cimg_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
+int cimg_engine_synchronize(cimg_engine*) { return 0; }
+
+int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
+                             const int32_t* nbytes, void* h_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
+{
+    if (n <= 0) return 0;
+    EmuCParams ep;
+    ep.typesize = p->typesize; ep.clevel = p->clevel; ep.blocksize = p->blocksize; ep.compcode = p->compcode; ep.splitmode = p->splitmode;
+    memcpy(ep.filters, p->filters, 6); memcpy(ep.filters_meta, p->filters_meta, 6);
+    // the emulated kernels write whole destsize windows: stage like the engine does
+    std::vector<int64_t> off((size_t)n);
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) { off[(size_t)i] = total; total += ((int64_t)destsize[i] + 63) & ~63ll; }
+    std::vector<uint8_t> stage((size_t)total + 64);
+    const int rc = emu_compress_batch(&ep, n, (const uint8_t*)h_raw, raw_off, nbytes, stage.data(), off.data(), destsize, cbytes);
+    if (rc < 0) { e->err = "emulated compress batch rejected, code " + std::to_string(rc); return rc; }
+    for (int i = 0; i < n; i++) if (cbytes[i] > 0) memcpy((uint8_t*)h_comp + comp_off[i], stage.data() + off[(size_t)i], (size_t)cbytes[i]);
+    return 0;
+}
+
+int cimg_decompress_batch_host(cimg_engine* e, int32_t n, const void* h_comp, const int64_t* comp_off, void* h_raw,
+                               const int64_t* raw_off, const int32_t* cap, int32_t* status)
+{
+    if (n <= 0) return 0;
+    std::vector<int32_t> nb((size_t)n), bs((size_t)n), st((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        const uint8_t* c = (const uint8_t*)h_comp + comp_off[i];
+        memcpy(&nb[(size_t)i], c + 4, 4); memcpy(&bs[(size_t)i], c + 8, 4);
+        if (c[0] > 5) { e->err = "format version"; return -10; }
+        if (bs[(size_t)i] <= 0 || (nb[(size_t)i] > 0 && bs[(size_t)i] > nb[(size_t)i]) || c[3] == 0) { e->err = "invalid header"; return -11; }
+        if (nb[(size_t)i] > cap[i]) { e->err = "buffer too small"; return -6; }
+    }
+    const int rc = emu_decompress_batch(n, (const uint8_t*)h_comp, comp_off, nb.data(), bs.data(), (uint8_t*)h_raw, raw_off, st.data());
+    if (status) memcpy(status, st.data(), sizeof(int32_t) * (size_t)n);
+    if (rc < 0) { e->err = "emulated decompress batch rejected"; return rc; }
+    for (int i = 0; i < n; i++) if (st[(size_t)i] < 0) { e->err = "chunk decode failed"; return st[(size_t)i]; }
+    return 0;
+}
+
+}  // extern "C"
