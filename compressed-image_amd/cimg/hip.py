@@ -254,7 +254,7 @@ class Engine:
         load().cimg_engine_debug_stamps(self.handle, 1 if on else 0)
 
     def read_stamps(self, which, max_workgroups=1 << 20):
-        out = np.zeros((max_workgroups, 8), np.uint64)
+        out = np.zeros((max_workgroups, 16), np.uint64)
         n = self._check(load().cimg_engine_read_stamps(self.handle, which, _ptr(out), max_workgroups))
         return out[:n]
 

@@ -26,6 +26,7 @@ struct AssembleArgs {
     const StreamRec* recs;
     uint8_t* comp;             // chunks are written at comp + desc.comp_off
     ChunkLayout* layout;       // per chunk
+    int32_t uniform_nblocks;   // > 0: every chunk has this many blocks
 };
 
 CIMG_DEV int rec_payload(const StreamRec& r) { return r.kind == REC_RUN ? (r.value > 0 ? 1 : 0) : r.csize; }
@@ -145,7 +146,7 @@ struct EmitBlock {
 
     CIMG_DEV void run(int wave)
     {
-        const int chunk = find_chunk(a.descs, a.nchunks, b);
+        const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
         const ChunkDesc& d = a.descs[chunk];
         const int j = b - d.blk0;
         uint8_t* c = a.comp + d.comp_off;

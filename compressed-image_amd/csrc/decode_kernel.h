@@ -33,6 +33,7 @@ struct DecodeArgs {
     int32_t* status;          // per chunk: 0 ok, <0 blosc2 error code
     int32_t lds_bytes;        // dynamic LDS size the launch provides
     uint64_t* dbg;            // diagnostics only: per-workgroup time stamps (nullptr in production)
+    int32_t uniform_nblocks;  // > 0: every chunk has this many blocks (chunk = block / uniform_nblocks)
 };
 
 CIMG_HD int round16(int x) { return (x + 15) & ~15; }
@@ -52,8 +53,9 @@ inline int decode_lds_bytes(int blocksize, int typesize)
 }
 
 // find the chunk that owns batch-wide block index b (descs are ordered by blk0)
-CIMG_DEV int find_chunk(const ChunkDesc* descs, int nchunks, int b)
+CIMG_DEV int find_chunk(const ChunkDesc* descs, int nchunks, int b, int uniform_nblocks = 0)
 {
+    if (uniform_nblocks > 0) return b / uniform_nblocks;
     int lo = 0, hi = nchunks - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -130,6 +132,64 @@ CIMG_DEV void wave_fill_global(uint8_t* dst, int nbytes, uint32_t byte, int wave
 // ---- LZ4 block decode by one wave, in place inside LDS ----------------------------------------------
 // Compressed bytes occupy [cs, cs + csize); output is written to [base, base + n).  Every LDS index is
 // clamped to lds_limit so a corrupt stream can produce garbage but never an out-of-range access.
+//
+// The token stream is read through a 256-byte register window (lane l holds the aligned dword at
+// wbase + 4l); the next 8 input bytes are pulled into a scalar with three v_readlane, so a whole short
+// sequence header (token, <= 5 literals, offset) is parsed with scalar shifts and its literals are
+// written straight from the scalar -- no LDS read on that path.  Matches with offset 1 (runs) are
+// fills; offsets < 64 replicate a pattern with one read; long copies move 256 bytes per step.
+CIMG_DEV void lds_copy_bytes(uint8_t* lds, int dst, int src, int len)
+{
+    // forward copy, dst < src or dst - src >= 64 (each 64-byte step reads before it writes)
+    for (int c = 0; c < len; c += 64) {
+        LV<uint32_t> t;
+        FOR_LANES(l) { if (c + l < len) t[l] = lds[src + c + l]; }
+        FOR_LANES_W(l) { if (c + l < len) lds[dst + c + l] = (uint8_t)t[l]; }
+    }
+}
+
+// dst - src >= 256 or dst < src - 256 (no overlap inside a 256-byte step)
+CIMG_DEV void lds_copy_wide(uint8_t* lds, int dst, int src, int len)
+{
+    const int head = imin((4 - (dst & 3)) & 3, len);
+    if (head) {
+        LV<uint32_t> t;
+        FOR_LANES(l) { if (l < head) t[l] = lds[src + l]; }
+        FOR_LANES_W(l) { if (l < head) lds[dst + l] = (uint8_t)t[l]; }
+    }
+    int done = head;
+    while (len - done >= 4) {
+        const int words = imin((len - done) >> 2, 64);
+        LV<uint32_t> t;
+        FOR_LANES(l) { if (l < words) t[l] = lds_ld32u(lds, src + done + 4 * l); }
+        FOR_LANES_W(l) { if (l < words) *reinterpret_cast<uint32_t*>(lds + dst + done + 4 * l) = t[l]; }
+        done += 4 * words;
+    }
+    if (done < len) {
+        const int tail = len - done;
+        LV<uint32_t> t;
+        FOR_LANES(l) { if (l < tail) t[l] = lds[src + done + l]; }
+        FOR_LANES_W(l) { if (l < tail) lds[dst + done + l] = (uint8_t)t[l]; }
+    }
+}
+
+CIMG_DEV void lds_fill_bytes(uint8_t* lds, int dst, int len, uint32_t byte)
+{
+    for (int c = 0; c < len; c += 64) {
+        FOR_LANES_W(l) { if (c + l < len) lds[dst + c + l] = (uint8_t)byte; }
+    }
+}
+
+// t mod m for 0 <= t < 128, 1 <= m < 64 (float reciprocal + one fix-up; exact in this range)
+CIMG_DEV int small_mod(int t, int m, float inv_m)
+{
+    int q = (int)((float)t * inv_m);
+    int r = t - q * m;
+    if (r < 0) r += m;
+    if (r >= m) r -= m;
+    return r;
+}
+
 CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, int lds_limit)
 {
     int ip = cs;
@@ -137,90 +197,263 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
     int op = base;
     const int oend = base + n;
     int wbase = -4096;
-    LV<uint32_t> wb;
-    const int clampmax = lds_limit - 1;
+    LV<uint32_t> win;
+    const int clampmax = (lds_limit - 4) & ~3;
 
-#define CIMG_PEEK(dst, at)                                                          \
-    do {                                                                            \
-        const int at_ = (at);                                                       \
-        if (at_ - wbase >= 64) {                                                    \
-            wbase = at_;                                                            \
-            FOR_LANES(l) { wb[l] = lds[imin(at_ + l, clampmax)]; }                  \
-        }                                                                           \
-        dst = readlane(wb, at_ - wbase);                                            \
+    // a match copy of <= 64 bytes whose source bytes have been requested but not yet stored: the next
+    // sequence's header is parsed (scalar work on the register window) while the LDS read is in flight
+    LV<uint32_t> pend;
+    int pend_dst = 0, pend_len = 0;
+#define CIMG_RETIRE()                                                                            \
+    do {                                                                                         \
+        if (pend_len) {                                                                          \
+            FOR_LANES_W(l) { if (l < pend_len) lds[pend_dst + l] = (uint8_t)pend[l]; }           \
+            pend_len = 0;                                                                        \
+        }                                                                                        \
+    } while (0)
+
+    // 8 input bytes starting at `at` as a scalar (bytes past the window / the stream are garbage the
+    // callers never use: every use is guarded by iend).  A reload reads LDS *behind* any pending store
+    // of output (ip stays ahead of op), so it does not need the pending copy retired first.
+#define CIMG_FETCH8(dst, at)                                                                     \
+    do {                                                                                         \
+        const int at_ = (at);                                                                    \
+        if (at_ - wbase > 256 - 12 || at_ < wbase) {                                             \
+            wbase = at_ & ~3;                                                                    \
+            FOR_LANES(l) { win[l] = *reinterpret_cast<const uint32_t*>(lds + imin(wbase + 4 * l, clampmax)); } \
+        }                                                                                        \
+        const int i_ = (at_ - wbase) >> 2;                                                       \
+        const uint64_t d0_ = readlane(win, i_), d1_ = readlane(win, i_ + 1), d2_ = readlane(win, i_ + 2); \
+        const int sh_ = (at_ & 3) * 8;                                                           \
+        dst = ((d0_ | (d1_ << 32)) >> sh_) | (sh_ ? (d2_ << (64 - sh_)) : 0);                    \
     } while (0)
 
     for (;;) {
         if (ip >= iend) return ERR_DATA;
-        uint32_t token;
-        CIMG_PEEK(token, ip);
-        ip++;
-        int lit = (int)(token >> 4);
-        if (lit == 15) {
-            uint32_t b;
-            do {
-                if (ip >= iend) return ERR_DATA;
-                CIMG_PEEK(b, ip);
-                ip++;
-                lit += (int)b;
-            } while (b == 255);
+        // ---- batch path: parse every "simple" sequence of the next 64 input bytes at once ------------------
+        // Every lane pretends a token starts at its byte and works out that sequence's header; a short
+        // scalar walk then follows the real token chain through those per-lane answers.  Literals of the
+        // whole batch are stored with one instruction, matches run in order from three v_readlane each.
+        if (iend - ip >= 24) {
+            CIMG_RETIRE();
+            LV<uint32_t> tb, o0, o1, ex;
+            LV<int> lit_l, nxt_l, len_l, off_l, ml_l;
+            LV<bool> good;
+            FOR_LANES(l) {
+                const int at = ip + l;
+                tb[l] = lds[imin(at, clampmax)];
+                lit_l[l] = (int)(tb[l] >> 4);
+                const int hp = imin(at + 1 + lit_l[l], clampmax);
+                o0[l] = lds[hp];
+                o1[l] = lds[hp + 1];
+                ex[l] = lds[hp + 2];
+            }
+            FOR_LANES(l) {
+                const int mln = (int)(tb[l] & 15);
+                const bool has_ext = mln == 15;
+                off_l[l] = (int)(o0[l] | (o1[l] << 8));
+                ml_l[l] = mln + 4 + (has_ext ? (int)ex[l] : 0);
+                nxt_l[l] = l + 1 + lit_l[l] + 2 + (has_ext ? 1 : 0);
+                len_l[l] = lit_l[l] + ml_l[l];
+                // whole header inside the window, a following token exists, lengths need no more bytes
+                good[l] = lit_l[l] < 15 && (!has_ext || ex[l] < 255) && nxt_l[l] <= 64 && ip + nxt_l[l] < iend && off_l[l] != 0;
+            }
+            const uint64_t goodmask = ballot(good);
+            uint64_t tokens = 0;
+            int s = 0, acc = 0;
+            LV<int> opos;
+            FOR_LANES(l) { opos[l] = 0; }
+            while (s < 64 && ((goodmask >> s) & 1)) {
+                const int ln = readlane(len_l, s);
+                if (acc + ln > oend - op) break;
+                writelane(opos, s, acc);
+                tokens |= 1ull << s;
+                acc += ln;
+                s = readlane(nxt_l, s);
+            }
+            if (tokens) {
+                // literals: lane j belongs to the last token at or before j - 1
+                LV<int> owner;
+                LV<bool> is_lit;
+                FOR_LANES(l) {
+                    const uint64_t below = tokens & ((1ull << l) - 1);
+                    owner[l] = below ? 63 - (int)__builtin_clzll(below) : 0;
+                    is_lit[l] = below != 0;
+                }
+                LV<int> own_lit, own_pos;
+                lane_gather(lit_l, owner, own_lit);
+                lane_gather(opos, owner, own_pos);
+                FOR_LANES_W(l) {
+                    const int k = l - owner[l] - 1;
+                    if (is_lit[l] && k < own_lit[l] && l < s) lds[op + own_pos[l] + k] = (uint8_t)tb[l];
+                }
+                // matches, in order
+                int bad = 0;
+                uint64_t todo = tokens;
+                while (todo) {
+                    const int t = ctz64(todo);
+                    todo &= todo - 1;
+                    const int dst = op + readlane(opos, t) + readlane(lit_l, t);
+                    const int offset = readlane(off_l, t);
+                    const int ml = readlane(ml_l, t);
+                    const int src = dst - offset;
+                    if (src < base) { bad = 1; break; }
+                    CIMG_RETIRE();
+                    if (ml <= 64) {
+                        if (offset >= ml) {
+                            FOR_LANES(l) { pend[l] = lds[src + (l < ml ? l : 0)]; }
+                        } else if (offset == 1) {
+                            FOR_LANES(l) { pend[l] = lds[src]; }
+                        } else {
+                            const float inv = 1.0f / (float)offset;
+                            FOR_LANES(l) { pend[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
+                        }
+                        pend_dst = dst;
+                        pend_len = ml;
+                    } else if (offset >= 256) {
+                        lds_copy_wide(lds, dst, src, ml);
+                    } else if (offset >= 64) {
+                        lds_copy_bytes(lds, dst, src, ml);
+                    } else if (offset == 1) {
+                        LV<uint32_t> tt;
+                        FOR_LANES(l) { tt[l] = lds[src]; }
+                        lds_fill_bytes(lds, dst, ml, readlane(tt, 0));
+                    } else {
+                        const int period = offset * ((63 + offset) / offset);
+                        const float inv = 1.0f / (float)offset;
+                        for (int c = 0; c < ml; c += 64) {
+                            LV<uint32_t> tt;
+                            FOR_LANES(l) { if (c + l < ml) tt[l] = (c == 0) ? lds[src + small_mod(l, offset, inv)] : lds[dst + c + l - period]; }
+                            FOR_LANES_W(l) { if (c + l < ml) lds[dst + c + l] = (uint8_t)tt[l]; }
+                        }
+                    }
+                }
+                if (bad) return ERR_DATA;
+                ip += s;
+                op += acc;
+                continue;
+            }
         }
-        if (lit > iend - ip || lit > oend - op) return ERR_DATA;
-        if (lit > 0) {
-            const int rel = ip - wbase;
-            if (rel >= 0 && rel + lit <= 64) {
-                FOR_LANES_W(l) { if (l >= rel && l < rel + lit) lds[op + (l - rel)] = (uint8_t)wb[l]; }
-            } else {
-                for (int c = 0; c < lit; c += 64) {
-                    LV<uint32_t> t;
-                    FOR_LANES(l) { if (c + l < lit) t[l] = lds[ip + c + l]; }
-                    FOR_LANES_W(l) { if (c + l < lit) lds[op + c + l] = (uint8_t)t[l]; }
+        uint64_t q;
+        CIMG_FETCH8(q, ip);
+        const uint32_t token = (uint32_t)(q & 0xFF);
+        int lit = (int)(token >> 4);
+        int ml = (int)(token & 15);
+        int offset;
+        const bool ext = ml == 15;
+        if ((lit <= 4 || (lit == 5 && !ext)) && iend - ip >= 8) {
+            // ---- short header: token, literals, offset (and one length byte) are all inside q ---------
+            const int hdr = 1 + lit + 2;
+            offset = (int)((q >> (8 * (1 + lit))) & 0xFFFF);
+            int extra = 0;
+            if (ext) {
+                extra = (int)((q >> (8 * hdr)) & 0xFF);
+                if (extra == 255) {
+                    // long match: more length bytes follow
+                    ip += hdr + 1;
+                    ml += 255;
+                    uint32_t b;
+                    do {
+                        if (ip >= iend) return ERR_DATA;
+                        uint64_t e;
+                        CIMG_FETCH8(e, ip);
+                        b = (uint32_t)(e & 0xFF);
+                        ip++;
+                        ml += (int)b;
+                    } while (b == 255);
+                    extra = -1;
+                } else {
+                    ml += extra;
                 }
             }
-            ip += lit;
-            op += lit;
+            if (extra >= 0) ip += hdr + (ext ? 1 : 0);
+            if (lit > oend - op) return ERR_DATA;
+            CIMG_RETIRE();
+            if (lit) {
+                const uint64_t lits = q >> 8;
+                FOR_LANES_W(l) { if (l < lit) lds[op + l] = (uint8_t)(lits >> (8 * (l & 7))); }
+                op += lit;
+            }
+        } else {
+            // ---- general header ----------------------------------------------------------------------------
+            CIMG_RETIRE();
+            ip++;
+            if (lit == 15) {
+                uint32_t b;
+                do {
+                    if (ip >= iend) return ERR_DATA;
+                    uint64_t e;
+                    CIMG_FETCH8(e, ip);
+                    b = (uint32_t)(e & 0xFF);
+                    ip++;
+                    lit += (int)b;
+                } while (b == 255);
+            }
+            if (lit > iend - ip || lit > oend - op) return ERR_DATA;
+            if (lit > 0) {
+                if (lit >= 512) lds_copy_wide(lds, op, ip, lit); else lds_copy_bytes(lds, op, ip, lit);   // op < ip - 32: forward copy is safe
+                ip += lit;
+                op += lit;
+            }
+            if (ip == iend) break;                              // a block ends with literals
+            if (iend - ip < 2) return ERR_DATA;
+            uint64_t e;
+            CIMG_FETCH8(e, ip);
+            offset = (int)(e & 0xFFFF);
+            ip += 2;
+            if (ext) {
+                uint32_t b;
+                do {
+                    if (ip >= iend) return ERR_DATA;
+                    CIMG_FETCH8(e, ip);
+                    b = (uint32_t)(e & 0xFF);
+                    ip++;
+                    ml += (int)b;
+                } while (b == 255);
+            }
         }
-        if (ip == iend) break;                              // a block ends with literals
-        if (iend - ip < 2) return ERR_DATA;
-        uint32_t o0, o1;
-        CIMG_PEEK(o0, ip);
-        CIMG_PEEK(o1, ip + 1);
-        ip += 2;
-        const int offset = (int)(o0 | (o1 << 8));
+        if (ip > iend) return ERR_DATA;
         if (offset == 0 || offset > op - base) return ERR_DATA;
-        int ml = (int)(token & 15);
-        if (ml == 15) {
-            uint32_t b;
-            do {
-                if (ip >= iend) return ERR_DATA;
-                CIMG_PEEK(b, ip);
-                ip++;
-                ml += (int)b;
-            } while (b == 255);
-        }
         ml += 4;
         if (ml > oend - op) return ERR_DATA;
         const int src = op - offset;
-        if (offset >= 64) {
-            for (int c = 0; c < ml; c += 64) {
-                LV<uint32_t> t;
-                FOR_LANES(l) { if (c + l < ml) t[l] = lds[src + c + l]; }
-                FOR_LANES_W(l) { if (c + l < ml) lds[op + c + l] = (uint8_t)t[l]; }
+        if (ml <= 64) {
+            // request the source bytes now, store them after the next header has been parsed
+            if (offset >= ml) {
+                FOR_LANES(l) { pend[l] = lds[src + (l < ml ? l : 0)]; }
+            } else if (offset == 1) {
+                FOR_LANES(l) { pend[l] = lds[src]; }
+            } else {
+                const float inv = 1.0f / (float)offset;
+                FOR_LANES(l) { pend[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
             }
+            pend_dst = op;
+            pend_len = ml;
+        } else if (offset >= 256 && ml >= 128) {
+            lds_copy_wide(lds, op, src, ml);
+        } else if (offset >= 64) {
+            lds_copy_bytes(lds, op, src, ml);
+        } else if (offset == 1) {
+            LV<uint32_t> t;
+            FOR_LANES(l) { t[l] = lds[src]; }
+            lds_fill_bytes(lds, op, ml, readlane(t, 0));
         } else {
             // overlapping match: byte t of the match equals pattern byte t mod offset
             const int period = offset * ((63 + offset) / offset);     // smallest multiple of offset >= 64
+            const float inv = 1.0f / (float)offset;
             for (int c = 0; c < ml; c += 64) {
                 LV<uint32_t> t;
                 FOR_LANES(l) {
-                    if (c + l < ml) t[l] = (c == 0) ? lds[src + (l % offset)] : lds[op + c + l - period];
+                    if (c + l < ml) t[l] = (c == 0) ? lds[src + small_mod(l, offset, inv)] : lds[op + c + l - period];
                 }
                 FOR_LANES_W(l) { if (c + l < ml) lds[op + c + l] = (uint8_t)t[l]; }
             }
         }
         op += ml;
     }
-#undef CIMG_PEEK
+    CIMG_RETIRE();
+#undef CIMG_FETCH8
+#undef CIMG_RETIRE
     return op == oend ? 0 : ERR_DATA;
 }
 
@@ -254,20 +487,24 @@ struct DecodeBlock {
 
     CIMG_DEV void phase_a(int wave)
     {
-        chunk = find_chunk(a.descs, a.nchunks, b);
+        chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
         const ChunkDesc& d = a.descs[chunk];
         j = b - d.blk0;
         c = a.comp + d.comp_off;
         out = a.raw + d.raw_off + (int64_t)j * d.blocksize;
         bsize = (j == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
         mode = 3;
-        const int flags = c[OFF_FLAGS];
-        ts = c[OFF_TYPESIZE];
-        const int nbytes = ld32s(c + OFF_NBYTES), blocksize = ld32s(c + OFF_BLOCKSIZE), cbytes = ld32s(c + OFF_CBYTES);
-        if (c[0] > 5) { fail(ERR_VERSION_SUPPORT); return; }
+        // the whole 32-byte header in one round trip (wave-uniform address)
+        const u128 h0 = ld128u(c), h1 = ld128u(c + 16);
+        const uint32_t w0 = uni(h0.x);
+        const int flags = (int)((w0 >> 16) & 0xFF);
+        ts = (int)(w0 >> 24);
+        const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z), cbytes = (int)uni(h0.w);
+        const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
+        if ((w0 & 0xFF) > 5) { fail(ERR_VERSION_SUPPORT); return; }
         if (nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN) { fail(ERR_INVALID_HEADER); return; }
         if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) { fail(ERR_VERSION_SUPPORT); return; }
-        const int special = (c[OFF_BLOSC2_FLAGS] >> 4) & 7;
+        const int special = (int)((b2 >> 28) & 7);
         if (special == SPECIAL_ZERO) { mode = 2; wave_fill_global(out, bsize, 0, wave, 4); return; }
         if (special != 0) { fail(ERR_DATA); return; }
         if (flags & FLAG_MEMCPYED) {
@@ -278,8 +515,8 @@ struct DecodeBlock {
         }
         if ((flags >> 5) != 1) { fail(ERR_CODEC_SUPPORT); return; }
         // filter pipeline: exactly one of {none, shuffle, bitshuffle}, in the last slot
-        filter = c[OFF_FILTERS + 5];
-        for (int i = 0; i < 5; i++) if (c[OFF_FILTERS + i] != 0) { fail(ERR_CODEC_SUPPORT); return; }
+        filter = (int)((f1 >> 8) & 0xFF);
+        if (f0 != 0 || (f1 & 0xFF) != 0) { fail(ERR_CODEC_SUPPORT); return; }
         if (filter != FILTER_NONE && filter != FILTER_SHUFFLE) { fail(ERR_CODEC_SUPPORT); return; }
         const bool leftover_blk = bsize != blocksize;
         ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;

@@ -47,6 +47,7 @@ struct EncodeArgs {
     int32_t want_split;       // 1: this launch encodes the planes of split blocks, 0: unsplit blocks
     uint64_t* dbg;            // diagnostics only: per-item time stamps (nullptr in production)
     uint32_t* queue;          // work-queue head, zeroed before the launch
+    int32_t uniform_nblocks;  // > 0: every chunk has this many blocks
 };
 
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
@@ -95,7 +96,9 @@ CIMG_DEV void emit_literals(const uint8_t* in, int from, uint8_t* out, int pos, 
 // result does not fit cap.  need_out = smallest cap that still succeeds.
 CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* out, int cap, int accel, int& need_out)
 {
-    uint16_t* tab16 = reinterpret_cast<uint16_t*>(tab);
+    // volatile: other lanes of the wave write the same slots, and the read-back after a write is exactly
+    // how collisions are detected -- the compiler must not forward the lane's own store to that load
+    volatile uint16_t* tab16 = reinterpret_cast<volatile uint16_t*>(tab);
     {
         const u128 z = {0, 0, 0, 0};
         for (int u0 = 0; u0 < LZ4_HASH_BYTES / 16; u0 += 64) {
@@ -121,6 +124,7 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             LV<int> pos;
             LV<bool> valid;
             LV<uint32_t> v, h, back;
+            const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
             FOR_LANES(l) {
                 const int t = t0 + l - pre;                       // probe number, -1 for the pre lane
                 // probe t sits at sstart + (t ? 1 + sum_{u<t-1} ((s64+u)>>6) : 0); the next one is one gap further
@@ -128,16 +132,14 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 const int gap = t <= 0 ? 1 : (s64 + t - 1) >> 6;
                 pos[l] = p;
                 valid[l] = t < 0 || p + gap <= mflimit_p1;
-                v[l] = valid[l] ? lds_ld32u(in, p) : 0u;
+                v[l] = lds_ld32u(in, valid[l] ? p : 0);
                 h[l] = lz4_hash(v[l]);
-                back[l] = pre ? lds_ld32u(in, sstart - 3) : 0u;     // the "put(ip - 2)" refill after a match
+                back[l] = lds_ld32u(in, backpos);
             }
             const int nv = popc64(ballot(valid));                 // valid lanes are a prefix
-            if (nv == 0) break;
-            CIMG_STAT(g_emu_windows);                                   // -> last literals
-            if (pre) {
-                FOR_LANES_W(l) { if (l == 0) tab16[lz4_hash(back[l])] = (uint16_t)(sstart - 3); }
-            }
+            if (nv == 0) break;                                   // -> last literals
+            CIMG_STAT(g_emu_windows);
+            FOR_LANES_W(l) { if (pre && l == 0) tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
             // a lane with the same hash as its left neighbour has that neighbour as candidate
             LV<uint32_t> ph, pv;
             LV<int> ppos;
@@ -149,14 +151,15 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             FOR_LANES(l) {
                 cont[l] = valid[l] && l > 0 && h[l] == ph[l];
                 head[l] = valid[l] && !cont[l];
-                old[l] = head[l] ? tab16[h[l]] : 0u;
+                old[l] = tab16[h[l]];                              // every lane reads (harmless), only heads use it
             }
             FOR_LANES_W(l) { if (head[l]) tab16[h[l]] = (uint16_t)pos[l]; }
             LV<bool> loser, hit;
             LV<int> cand;
             FOR_LANES(l) {
-                const uint32_t rb = head[l] ? tab16[h[l]] : 0u;
-                const uint32_t mv = head[l] ? lds_ld32u(in, (int)old[l]) : pv[l];
+                const uint32_t rb = tab16[h[l]];
+                const uint32_t mvh = lds_ld32u(in, (int)old[l]);
+                const uint32_t mv = head[l] ? mvh : pv[l];
                 loser[l] = head[l] && rb != (uint32_t)pos[l];
                 hit[l] = valid[l] && mv == v[l];
                 cand[l] = head[l] ? (int)old[l] : ppos[l];
@@ -457,7 +460,7 @@ struct EncodeStream {
             b = item; s = 0;
         }
         if (b >= a.total_blocks) return;
-        const int chunk = find_chunk(a.descs, a.nchunks, b);
+        const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
         const ChunkDesc& d = a.descs[chunk];
         if (d.memcpyed) return;
         const int j = b - d.blk0;

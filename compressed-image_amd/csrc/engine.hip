@@ -46,9 +46,11 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
     blk.phase_a(wave);
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 1);       // stream 0 staged
+    if (wave == 1) debug_stamp(a.dbg, (int)blockIdx.x, 2);       // stream 1 staged
     __syncthreads();
     blk.phase_b(wave);
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 1);
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
 }
 
 // ====================================================================================================
@@ -280,13 +282,13 @@ int cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_
 }
 
 // diagnostics: per-workgroup {shader clock, 100 MHz clock, HW_ID, XCC_ID} x {start, end} of the most recent
-// encode (which = 0) or decode (which = 1) launch; 8 uint64 per workgroup.  Returns the workgroup count.
+// encode (which = 0) or decode (which = 1) launch; 16 uint64 per workgroup (four stamps).  Returns the workgroup count.
 void cimg_engine_debug_stamps(cimg_engine* e, int on) { e->stamps = on != 0; }
 int cimg_engine_read_stamps(cimg_engine* e, int which, uint64_t* out, int max_workgroups)
 {
     if (which < 0 || which > 1 || !e->dbg.p) return 0;
     const int n = e->dbg_count[which] < max_workgroups ? e->dbg_count[which] : max_workgroups;
-    if (cimg_memcpy_d2h(e, out, e->dbg.p, (size_t)n * 64)) return ERR_FAILURE;
+    if (cimg_memcpy_d2h(e, out, e->dbg.p, (size_t)n * 128)) return ERR_FAILURE;
     return n;
 }
 
@@ -330,7 +332,7 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
         if ((rc = e->hip(hipMemsetAsync(head, 0, sizeof(uint32_t), e->stream), "queue memset"))) return rc;
         EncodeArgs ea{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
-                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head};
+                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks};
         if ((rc = e->allow_lds(cimg_encode_streams, 0, lds_bytes))) return rc;
         // persistent workgroups: as many as are resident at once, never more than there are items
         if (e->enc_wgs_lds[split] != lds_bytes) {
@@ -344,7 +346,7 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
         if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_streams, ea, grid, 64, lds_bytes))) return rc;
     }
     AssembleArgs aa{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
-                    (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p};
+                    (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks};
     if ((rc = e->launch(CIMG_K_LAYOUT, cimg_layout_chunks, aa, nchunks, 64, 0))) return rc;
     if ((rc = e->launch(CIMG_K_EMIT, cimg_emit_blocks, aa, plan.total_blocks, 256, 0))) return rc;
     if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->layout.p, sizeof(ChunkLayout) * (size_t)nchunks, hipMemcpyDeviceToHost, e->stream), "layout D2H"))) return rc;
@@ -375,12 +377,12 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     if ((rc = e->hip(hipMemsetAsync(e->status.p, 0, st_bytes, e->stream), "status memset"))) return rc;
     uint64_t* dbg = nullptr;
     if (e->stamps) {
-        if ((rc = e->reserve(e->dbg, (size_t)plan.total_blocks * 64))) return rc;
-        if ((rc = e->hip(hipMemsetAsync(e->dbg.p, 0, (size_t)plan.total_blocks * 64, e->stream), "dbg memset"))) return rc;
+        if ((rc = e->reserve(e->dbg, (size_t)plan.total_blocks * 128))) return rc;
+        if ((rc = e->hip(hipMemsetAsync(e->dbg.p, 0, (size_t)plan.total_blocks * 128, e->stream), "dbg memset"))) return rc;
         dbg = (uint64_t*)e->dbg.p;
         e->dbg_count[1] = plan.total_blocks;
     }
-    DecodeArgs da{(const ChunkDesc*)e->descs.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, (int32_t*)e->status.p, plan.lds_bytes, dbg};
+    DecodeArgs da{(const ChunkDesc*)e->descs.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, (int32_t*)e->status.p, plan.lds_bytes, dbg, plan.uniform_nblocks};
     if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
     if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
     if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->status.p, st_bytes, hipMemcpyDeviceToHost, e->stream), "status D2H"))) return rc;

@@ -96,12 +96,20 @@ inline int plan_chunk(const HostCParams& p, int32_t nbytes, int32_t destsize, Ch
 
 namespace cimg {
 
+inline int uniform_blocks(const std::vector<ChunkDesc>& descs)
+{
+    if (descs.empty() || descs[0].nblocks <= 0) return 0;
+    for (const auto& d : descs) if (d.nblocks != descs[0].nblocks) return 0;
+    return descs[0].nblocks;
+}
+
 struct EncodePlan {
     std::vector<ChunkDesc> descs;
     CodecParams cp{};
     int32_t total_blocks = 0;
     int32_t lds_split = 0;      // LDS per stream workgroup of the split-block launch (0: no such blocks)
     int32_t lds_unsplit = 0;    // same for the unsplit-block launch (leftover blocks, dont-split chunks)
+    int32_t uniform_nblocks = 0; // > 0: every chunk has this many blocks
 };
 
 enum : int { MAX_LDS_BYTES = 160 * 1024 };
@@ -147,6 +155,7 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
     }
     if (plan->lds_split > MAX_LDS_BYTES || plan->lds_unsplit > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
     plan->total_blocks = blk;
+    plan->uniform_nblocks = uniform_blocks(plan->descs);
     cp.slot_bytes = (cp.max_blocksize + 63) & ~63;
     return 0;
 }
@@ -155,6 +164,7 @@ struct DecodePlan {
     std::vector<ChunkDesc> descs;
     int32_t total_blocks = 0;
     int32_t lds_bytes = 0;
+    int32_t uniform_nblocks = 0;
 };
 
 inline int decode_lds_bound(int blocksize)
@@ -189,6 +199,7 @@ inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t
     if (lds > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
     plan->total_blocks = blk;
     plan->lds_bytes = lds;
+    plan->uniform_nblocks = uniform_blocks(plan->descs);
     return 0;
 }
 

@@ -68,6 +68,13 @@ inline void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
 }
 inline int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
 inline void debug_stamp(uint64_t*, int, int) {}
+template <class T> inline void writelane(LV<T>& x, int lane, T value) { x.v[lane & 63] = value; }
+template <class T> inline void lane_gather(const LV<T>& x, const LV<int>& idx, LV<T>& out)
+{
+    T tmp[64];
+    for (int l = 0; l < 64; ++l) tmp[l] = x.v[idx.v[l] & 63];
+    for (int l = 0; l < 64; ++l) out.v[l] = tmp[l];
+}
 inline uint32_t queue_pop(uint32_t* head) { return (*head)++; }
 // value held by lane l-1 (lane 0 keeps its own)
 template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
@@ -128,9 +135,20 @@ CIMG_DEV int wave_max(const LV<int>& x)
     for (int d = 32; d >= 1; d >>= 1) { const int n = __shfl_xor(v, d); v = n > v ? n : v; }
     return __builtin_amdgcn_readfirstlane(v);
 }
+template <class T> CIMG_DEV void writelane(LV<T>& x, int lane, T value)
+{
+    static_assert(sizeof(T) == 4, "writelane moves one dword");
+    x.v = ((int)__lane_id() == lane) ? value : x.v;
+}
+// out[l] = x[idx[l]] (ds_bpermute: LDS crossbar, no memory access)
+template <class T> CIMG_DEV void lane_gather(const LV<T>& x, const LV<int>& idx, LV<T>& out)
+{
+    static_assert(sizeof(T) == 4, "lane_gather moves one dword");
+    out.v = (T)__builtin_amdgcn_ds_bpermute(idx.v << 2, (int)x.v);
+}
 // one returning device-scope atomic on the queue head (MI355X_MICROARCH.md: 'dequeue', ~0.3-1.1 us)
 CIMG_DEV uint32_t queue_pop(uint32_t* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// diagnostic builds only (dbg != nullptr): slot[4*w + which] = {shader clock, 100 MHz wall clock | hw id}
+// diagnostic builds only (dbg != nullptr): slot[16*w + 4*which], which = 0..3 = {shader clock, 100 MHz wall clock | hw id}
 CIMG_DEV void debug_stamp(uint64_t* dbg, int w, int which)
 {
     if (dbg == nullptr) return;
@@ -139,17 +157,22 @@ CIMG_DEV void debug_stamp(uint64_t* dbg, int w, int which)
     const uint32_t hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
     const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));
     if (__lane_id() == 0) {
-        dbg[8 * (size_t)w + 4 * which + 0] = t;
-        dbg[8 * (size_t)w + 4 * which + 1] = r;
-        dbg[8 * (size_t)w + 4 * which + 2] = hw;
-        dbg[8 * (size_t)w + 4 * which + 3] = xcc;
+        dbg[16 * (size_t)w + 4 * which + 0] = t;
+        dbg[16 * (size_t)w + 4 * which + 1] = r;
+        dbg[16 * (size_t)w + 4 * which + 2] = hw;
+        dbg[16 * (size_t)w + 4 * which + 3] = xcc;
     }
 }
 // value held by lane l-1 (lane 0 keeps its own)
 template <class T> CIMG_DEV void lane_prev(const LV<T>& x, LV<T>& out)
 {
     static_assert(sizeof(T) == 4, "lane_prev moves one dword");
+    // DPP wave_shr:1 -- one VALU op, no LDS-pipe round trip (a ds_bpermute would cost ~100 cycles here)
+#ifdef CIMG_LANE_PREV_BPERMUTE
     out.v = (T)__shfl_up((int)x.v, 1);
+#else
+    out.v = (T)__builtin_amdgcn_update_dpp((int)x.v, (int)x.v, 0x138, 0xF, 0xF, false);
+#endif
 }
 
 }  // namespace cimg

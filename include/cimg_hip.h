@@ -101,7 +101,8 @@ int  cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64
 const char* cimg_kernel_name(int kernel);
 
 /* ---- diagnostics: per-workgroup clock stamps of the most recent encode (0) / decode (1) launch ------
- * 8 uint64 per workgroup: {shader clock, 100 MHz clock, HW_ID, XCC_ID} at start, then at end.  Off by
+ * 16 uint64 per workgroup: four stamps of {shader clock, 100 MHz clock, HW_ID, XCC_ID} (start, stream 0
+ * staged, stream 1 staged, end).  Off by
  * default; when on, the NEXT launches stamp (the dbg pointer is null otherwise and the kernels skip it). */
 void cimg_engine_debug_stamps(cimg_engine* e, int on);
 int  cimg_engine_read_stamps(cimg_engine* e, int which, uint64_t* out, int max_workgroups);

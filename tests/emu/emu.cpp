@@ -46,14 +46,14 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         if (!lds_bytes) continue;
         std::vector<uint8_t> lds((size_t)lds_bytes + 64);
         uint32_t queue = 0;
-        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue};
+        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
             EncodeStream es(ea, lds.data(), w);
             es.run();
         }
     }
-    AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data()};
+    AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks};
     for (int c = 0; c < nchunks; c++) { LayoutChunk lc(aa, c); lc.run(); }
     for (int b = 0; b < plan.total_blocks; b++) { EmitBlock eb(aa, b); for (int w = 0; w < 4; w++) eb.run(w); }
     for (int c = 0; c < nchunks; c++) cbytes[c] = layout[(size_t)c].cbytes;
@@ -68,7 +68,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     if (rc < 0) return rc;
     memset(status, 0, sizeof(int32_t) * (size_t)nchunks);
     std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
-    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr};
+    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks};
     for (int b = 0; b < plan.total_blocks; b++) {
         memset(lds.data(), 0xCD, lds.size());
         DecodeBlock blk(da, lds.data(), b);
