@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libcimg_hip.so")
+LIB_PATH = os.environ.get("CIMG_LIB") or os.path.join(_PKG, "libcimg_hip.so")   # CIMG_LIB: diagnostic builds
 
 K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE = 0, 1, 2, 3
 KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")

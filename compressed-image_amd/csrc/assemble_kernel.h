@@ -58,7 +58,7 @@ struct LayoutChunk {
 
     CIMG_DEV void run()
     {
-        const ChunkDesc& d = a.descs[chunk];
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
         uint8_t* c = a.comp + d.comp_off;
         ChunkLayout lay;
         lay.cbytes = 0; lay.mode = 3;
@@ -147,10 +147,10 @@ struct EmitBlock {
     CIMG_DEV void run(int wave)
     {
         const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
-        const ChunkDesc& d = a.descs[chunk];
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
         const int j = b - d.blk0;
         uint8_t* c = a.comp + d.comp_off;
-        const int mode = a.layout[chunk].mode;
+        const int mode = uni(a.layout[chunk].mode);
         const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
         const int bsize = leftover_blk ? d.leftover : d.blocksize;
         if (mode == 1) {
@@ -161,9 +161,10 @@ struct EmitBlock {
         const int ns = (d.split && !leftover_blk) ? a.p.typesize : 1;
         const int neblock = bsize / ns;
         const uint8_t* slot = a.scratch + (int64_t)b * a.p.slot_bytes;
-        int pos = ld32s(c + HEADER_LEN + 4 * j);
+        int pos = uni(ld32s(c + HEADER_LEN + 4 * j));
         for (int s = 0; s < ns; s++) {
-            const StreamRec r = a.recs[(int64_t)b * a.p.streams_per_block + s];
+            StreamRec r = a.recs[(int64_t)b * a.p.streams_per_block + s];
+            r.kind = uni(r.kind); r.value = uni(r.value); r.csize = uni(r.csize);
             if (wave == 0) {
                 const int word = r.kind == REC_RUN ? -r.value : r.csize;
                 FOR_LANES(l) {

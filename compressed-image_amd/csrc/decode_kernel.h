@@ -52,6 +52,25 @@ inline int decode_lds_bytes(int blocksize, int typesize)
     return a + 32;
 }
 
+// A chunk descriptor read by every lane from the same address is wave-uniform, but the compiler cannot
+// know that (vector loads land in VGPRs) and would treat everything derived from it -- block geometry,
+// early exits, loop bounds -- as divergent, wrapping uniform control flow in exec-mask bookkeeping.
+// Passing each field through v_readfirstlane pins it to SGPRs.
+CIMG_DEV int64_t uni64(int64_t x)
+{
+    const uint32_t lo = uni((uint32_t)(uint64_t)x), hi = uni((uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+CIMG_DEV ChunkDesc uniform_desc(const ChunkDesc* p)
+{
+    ChunkDesc d = *p;
+    d.raw_off = uni64(d.raw_off); d.comp_off = uni64(d.comp_off);
+    d.nbytes = uni(d.nbytes); d.destsize = uni(d.destsize); d.blocksize = uni(d.blocksize); d.nblocks = uni(d.nblocks);
+    d.leftover = uni(d.leftover); d.blk0 = uni(d.blk0); d.flags = uni(d.flags); d.split = uni(d.split);
+    d.memcpyed = uni(d.memcpyed); d.nstreams = uni(d.nstreams);
+    return d;
+}
+
 // find the chunk that owns batch-wide block index b (descs are ordered by blk0)
 CIMG_DEV int find_chunk(const ChunkDesc* descs, int nchunks, int b, int uniform_nblocks = 0)
 {
@@ -59,7 +78,7 @@ CIMG_DEV int find_chunk(const ChunkDesc* descs, int nchunks, int b, int uniform_
     int lo = 0, hi = nchunks - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+        if (uni(descs[mid].blk0) <= b) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
@@ -488,7 +507,7 @@ struct DecodeBlock {
     CIMG_DEV void phase_a(int wave)
     {
         chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
-        const ChunkDesc& d = a.descs[chunk];
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
         j = b - d.blk0;
         c = a.comp + d.comp_off;
         out = a.raw + d.raw_off + (int64_t)j * d.blocksize;

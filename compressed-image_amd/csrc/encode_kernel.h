@@ -71,21 +71,39 @@ extern long g_emu_windows, g_emu_matches, g_emu_collisions;   // test-side stati
 #define CIMG_STAT(x) ((void)0)
 #endif
 
+// -DCIMG_PROFILE (diagnostic builds only): per-item cycle accounting written to EncodeArgs::dbg
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+#define CIMG_PROF_DECL unsigned long long prof_t_ = cimg_cycles(); unsigned long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int prof_cnt_[4] = {0, 0, 0, 0}
+#ifndef CIMG_PROFILE_MASK
+#define CIMG_PROFILE_MASK 0xFF
+#endif
+#define CIMG_PROF_LAP(i) do { if ((CIMG_PROFILE_MASK >> (i)) & 1) { const unsigned long long n_ = cimg_cycles(); prof_acc_[i] += n_ - prof_t_; prof_t_ = n_; } } while (0)
+#define CIMG_PROF_COUNT(i) (++prof_cnt_[i])
+#define CIMG_PROF_STORE(dbg, item) do { if (dbg && __lane_id() == 0) { for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + k_] = prof_acc_[k_]; for (int k_ = 0; k_ < 4; k_++) dbg[16 * (size_t)(item) + 8 + k_] = (unsigned long long)prof_cnt_[k_]; } } while (0)
+#else
+#define CIMG_PROF_DECL
+#define CIMG_PROF_LAP(i) ((void)0)
+#define CIMG_PROF_COUNT(i) ((void)0)
+#define CIMG_PROF_STORE(dbg, item) ((void)0)
+#endif
+
 CIMG_DEV uint32_t lz4_hash(uint32_t v) { return (v * 2654435761u) >> 19; }
 // sum_{x=0}^{n-1} (x >> 6)
 CIMG_DEV int skip_prefix(int n) { const int q = n >> 6, r = n & 63; return q * (32 * (q - 1) + r); }
 
 // write an LZ4 length extension for `rem` (rem/255 times 255, then rem%255) at out[pos..)
-CIMG_DEV void emit_len_ext(uint8_t* out, int pos, int rem)
+CIMG_DEV void emit_len_ext(cimg_global_u8p out, int pos, int rem)
 {
     const int n255 = rem / 255, last = rem - 255 * n255;
+#pragma unroll 1
     for (int c = 0; c <= n255; c += 64) {
         FOR_LANES(l) { if (c + l <= n255) out[pos + c + l] = (uint8_t)(c + l < n255 ? 255 : last); }
     }
 }
 
-CIMG_DEV void emit_literals(const uint8_t* in, int from, uint8_t* out, int pos, int count)
+CIMG_DEV void emit_literals(const uint8_t* in, int from, cimg_global_u8p out, int pos, int count)
 {
+#pragma unroll 1
     for (int c = 0; c < count; c += 64) {
         FOR_LANES(l) { if (c + l < count) out[pos + c + l] = in[from + c + l]; }
     }
@@ -94,11 +112,15 @@ CIMG_DEV void emit_literals(const uint8_t* in, int from, uint8_t* out, int pos, 
 // Bit-exact LZ4_compress_fast(in, out, n, cap, accel) in limited-output mode, byU16 table, by one wave.
 // in: LDS plane (8 readable bytes past the end), tab: 16 KiB LDS.  Returns bytes written, 0 if the
 // result does not fit cap.  need_out = smallest cap that still succeeds.
-CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* out, int cap, int accel, int& need_out)
+CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* out_generic, int cap, int accel, int& need_out, uint64_t* dbg = nullptr, int item = 0)
 {
+    cimg_global_u8p out = CIMG_AS_GLOBAL(out_generic);
+    CIMG_PROF_DECL;
+    (void)dbg; (void)item;
+
     // volatile: other lanes of the wave write the same slots, and the read-back after a write is exactly
     // how collisions are detected -- the compiler must not forward the lane's own store to that load
-    volatile uint16_t* tab16 = reinterpret_cast<volatile uint16_t*>(tab);
+    cimg_lds_vu16p tab16 = CIMG_AS_LDS_VU16(tab);
     {
         const u128 z = {0, 0, 0, 0};
         for (int u0 = 0; u0 < LZ4_HASH_BYTES / 16; u0 += 64) {
@@ -116,10 +138,13 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             FOR_LANES(l) { v0[l] = lds_ld32u(in, 0); }
             FOR_LANES_W(l) { if (l == 0) tab16[lz4_hash(v0[l])] = 0; }
         }
+        CIMG_PROF_LAP(0);                                  // table clear + first byte
         int sstart = 1;     // search start position
         int t0 = 0;         // probes of this search already committed
         int pre = 0;        // 1: lane 0 is the probe right after a match (position sstart - 1)
+        int guard = 0;      // every wave must reach an exit: a window commits at least one probe, so n + 2 windows is a hard bound
         for (;;) {
+            if (++guard > n + 2) return -1;
             // ---- lay the window out ------------------------------------------------------------------
             LV<int> pos;
             LV<bool> valid;
@@ -137,8 +162,74 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 back[l] = lds_ld32u(in, backpos);
             }
             const int nv = popc64(ballot(valid));                 // valid lanes are a prefix
+            CIMG_PROF_LAP(1);                                   // positions + v read
             if (nv == 0) break;                                   // -> last literals
             CIMG_STAT(g_emu_windows);
+            // ---- run fast path ------------------------------------------------------------------------------
+            // The probe right after a match very often lands on the first byte of a run (flat image areas:
+            // high byte planes, masks, alpha).  Then probe 0 of the new search has the same four bytes, the
+            // same hash and -- unless the post-match probe itself matches -- is a match at offset 1.  That
+            // outcome needs only the post-match probe's own table slot, so the 64-lane window machinery is
+            // skipped: slot read + run-length scan in one LDS round trip, candidate check in a second.
+            int ip = 0, mp = 0, mcode = 0, backrun = 0;
+            bool zero_lit = false, have_match = false, extended = false;
+            if (pre && nv >= 2) {
+                const uint32_t v0 = readlane(v, 0), v1 = readlane(v, 1);
+                if (v0 == v1) {
+                    const int ip0 = sstart - 1;
+                    const uint32_t h0 = lz4_hash(v0);
+                    const uint32_t bbbb = (v0 & 0xFF) * 0x01010101u;            // v0 == v1 means v0 is four equal bytes
+                    FOR_LANES_W(l) { if (l == 0) tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
+                    LV<uint32_t> slot, scan;
+                    LV<uint32_t> before;
+                    FOR_LANES(l) {
+                        slot[l] = tab16[h0];
+                        scan[l] = lds_ld32u(in, ip0 + 5 + 4 * l);                 // bytes after the five known run bytes
+                        before[l] = in[ip0 - 1];
+                    }
+                    const int old0 = (int)readlane(slot, 0);
+                    LV<uint32_t> cv;
+                    FOR_LANES(l) { cv[l] = lds_ld32u(in, old0); }
+                    const bool hit0 = readlane(cv, 0) == v0;
+                    have_match = true;
+                    CIMG_STAT(g_emu_matches);
+                    if (hit0) {
+                        // zero-literal match at the post-match probe; its length depends on the candidate
+                        FOR_LANES_W(l) { if (l == 0) tab16[h0] = (uint16_t)ip0; }
+                        ip = ip0; mp = old0; zero_lit = true;
+                    } else {
+                        FOR_LANES_W(l) { if (l == 0) tab16[h0] = (uint16_t)(ip0 + 1); }
+                        ip = ip0 + 1; mp = ip0; zero_lit = false; extended = true;
+                        backrun = (readlane(before, 0) == (v0 & 0xFF)) ? 1 : 0;      // room is min(ip - anchor, mp) = 1
+                        // offset-1 match: it runs to the end of the run (or matchlimit)
+                        const int maxc = matchlimit - (ip + 4);
+                        for (int scans = 0;; ++scans) {
+                            if (scans > n / 256 + 2) return -2;
+                            LV<int> len;
+                            LV<bool> stop;
+                            FOR_LANES(l) {
+                                const int k = mcode + 4 * l;
+                                int vb = maxc - k;
+                                vb = vb < 0 ? 0 : (vb > 4 ? 4 : vb);
+                                int ln = 0;
+                                if (vb > 0) {
+                                    const uint32_t x = scan[l] ^ bbbb;
+                                    ln = x ? (int)(__builtin_ctz(x) >> 3) : 4;
+                                    if (ln > vb) ln = vb;
+                                }
+                                len[l] = ln;
+                                stop[l] = ln < 4;
+                            }
+                            const uint64_t sm = ballot(stop);
+                            if (sm) { const int f = ctz64(sm); mcode += 4 * f + readlane(len, f); break; }
+                            mcode += 256;
+                            FOR_LANES(l) { scan[l] = lds_ld32u(in, ip + 4 + mcode + 4 * l); }
+                        }
+                    }
+                }
+            }
+            if (have_match) { CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0); }   // run path
+            if (!have_match) {
             FOR_LANES_W(l) { if (pre && l == 0) tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
             // a lane with the same hash as its left neighbour has that neighbour as candidate
             LV<uint32_t> ph, pv;
@@ -191,22 +282,23 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     if (cont[l] && l <= B && (l == B || !((contmask >> ((l + 1) & 63)) & 1) || l == 63)) tab16[h[l]] = (uint16_t)pos[l];
                 }
             }
+            CIMG_PROF_LAP(3); CIMG_PROF_COUNT(1);               // window machinery
             if (m < 0) {
                 if (B + 1 < 64 && B + 1 >= nv) break;             // the next probe would pass mflimit
                 t0 += B + 1 - pre;
                 pre = 0;
                 continue;
             }
-
             CIMG_STAT(g_emu_matches);
-            // ---- a match at lane m: extend both ways with one LDS round trip ----------------------------------
-            int ip = readlane(pos, m);
-            int mp = readlane(cand, m);
-            const bool zero_lit = pre && m == 0;
+            ip = readlane(pos, m);
+            mp = readlane(cand, m);
+            zero_lit = pre && m == 0;
+            }   // !have_match (window path)
+
+            // ---- a match at ip with candidate mp: extend both ways with one LDS round trip ---------------------
+            if (!extended) {
             const int room = zero_lit ? 0 : imin(ip - anchor, mp);
             const int maxc = matchlimit - (ip + 4);
-            int mcode = 0, backrun = 0;
-            {
                 LV<bool> eq, stop;
                 LV<int> len;
                 FOR_LANES(l) {
@@ -258,7 +350,8 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         if (r < 64) break;
                     }
                 }
-            }
+            }   // !extended
+            CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);               // match extension
             ip -= backrun; mp -= backrun; mcode += backrun;
             const int lit = zero_lit ? 0 : ip - anchor;
             // ---- budget checks (limited-output rules) -------------------------------------------------------
@@ -301,6 +394,7 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             op = q;
             ip += mcode + 4;
             anchor = ip;
+            CIMG_PROF_LAP(5);                                   // budget checks + emit
             if (ip >= mflimit_p1) break;
             sstart = ip + 1;
             t0 = 0;
@@ -320,8 +414,23 @@ CIMG_DEV int lz4_encode_wave(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
         emit_literals(in, anchor, out, op, run);
         op += run;
     }
+    CIMG_PROF_LAP(6);                                       // last literals
+    CIMG_PROF_STORE(dbg, item);
     need_out = need;
     return op;
+}
+
+// Out of line on the GPU: the persistent workgroup loop around it keeps a lot of scalar state alive, and
+// inlining this body there pushed the kernel into SGPR spilling.  lds_passed is only used by the emulator.
+CIMG_DEV_NOINLINE int lz4_encode_wave(uint8_t* lds_passed, int in_off, int tab_off, int n, uint8_t* out, int cap, int accel, int* need_ptr, uint64_t* dbg = nullptr, int item = 0)
+{
+    uint8_t* const lds_base = CIMG_LDS_BASE(lds_passed);
+    const uint8_t* in = lds_base + in_off;
+    uint8_t* tab = lds_base + tab_off;
+    int need_out = 0;
+    const int result = lz4_encode_body(in, tab, n, out, cap, accel, need_out, dbg, item);
+    *need_ptr = need_out;
+    return result;
 }
 
 // true if all n bytes of the LDS plane equal its first byte
@@ -439,11 +548,12 @@ struct EncodeStream {
     CIMG_DEV void run()
     {
         const int items = encode_items(a.total_blocks, a.p.streams_per_block, a.want_split != 0);
-        for (;;) {
+        // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
+        for (int pops = 0; pops <= items; ++pops) {
             LV<uint32_t> got;
             FOR_LANES(l) { got[l] = 0; }
             FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(a.queue); }
-            const int item = (int)readlane(got, 0);
+            const int item = uni((int)readlane(got, 0));
             if (item >= items) return;
             run_item(item);
         }
@@ -461,7 +571,7 @@ struct EncodeStream {
         }
         if (b >= a.total_blocks) return;
         const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
-        const ChunkDesc& d = a.descs[chunk];
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
         if (d.memcpyed) return;
         const int j = b - d.blk0;
         const int ts = a.p.typesize;
@@ -469,7 +579,7 @@ struct EncodeStream {
         const int bsize = leftover_blk ? d.leftover : d.blocksize;
         const int ns = (d.split && !leftover_blk) ? ts : 1;
         if ((ns > 1) != (a.want_split != 0) || s >= ns) return;
-        debug_stamp(a.dbg, item, 0);
+
         const int neblock = bsize / ns;
         const uint8_t* src = a.raw + d.raw_off + (int64_t)j * d.blocksize;
         const bool shuf = a.p.filter == FILTER_SHUFFLE && ts > 1;
@@ -477,7 +587,6 @@ struct EncodeStream {
         else load_block(src, bsize, ts, shuf);
 
         const uint8_t* in = lds;
-        uint8_t* tab = lds + round16(neblock);
         uint8_t* out = a.scratch + (int64_t)b * a.p.slot_bytes + (int64_t)s * neblock;
         StreamRec r;
         r.kind = REC_RAW; r.value = 0; r.csize = neblock; r.need = 0;
@@ -486,16 +595,17 @@ struct EncodeStream {
             r.kind = REC_RUN; r.value = (int32_t)value; r.csize = 0;
         } else {
             int need = 0;
-            const int cb = lz4_encode_wave(in, tab, neblock, out, neblock, a.p.accel, need);
+            const int cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, a.p.accel, &need, a.dbg, item);
             if (cb > 0 && cb < neblock) {
                 r.kind = REC_LZ4; r.csize = cb; r.need = need;
             } else {
+                if (cb < 0) r.value = cb;                 // a loop guard tripped: stored raw, flagged for diagnosis
                 wave_copy_l2g(lds, 0, out, neblock);
             }
         }
         StreamRec* dst = a.recs + (int64_t)b * spb + s;
         FOR_LANES(l) { if (l == 0) *dst = r; }
-        debug_stamp(a.dbg, item, 1);
+
     }
 };
 

@@ -82,6 +82,7 @@ struct cimg_engine {
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
     int enc_wgs_lds[2] = {-1, -1};
     bool stamps = false;
+    bool trace = getenv("CIMG_TRACE") != nullptr;
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
     int max_dyn_lds[2] = {0, 0};      // largest dynamic LDS already enabled for encode / decode
@@ -158,6 +159,12 @@ struct cimg_engine {
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3((unsigned)block), (size_t)lds, stream, args);
         int rc = hip(hipGetLastError(), cimg_kernel_name(kid));
         if (timing) { (void)hipEventRecord(ev.b, stream); pending[kid].push_back(ev); }
+        if (!rc && trace) {             // CIMG_TRACE=1: find the launch that does not come back
+            fprintf(stderr, "[cimg] launched %s grid %d block %d lds %d ... ", cimg_kernel_name(kid), grid, block, lds);
+            fflush(stderr);
+            rc = hip(hipStreamSynchronize(stream), cimg_kernel_name(kid));
+            fprintf(stderr, "done (%d)\n", rc);
+        }
         return rc;
     }
     template <class Args>
@@ -327,7 +334,15 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;                     // no blocks of that kind in the batch
         const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0);
-        uint64_t* dbg = nullptr;    // in-kernel stamps of the persistent encode kernel are disabled (they wedge the launch; decode stamps work)
+        uint64_t* dbg = nullptr;
+#ifdef CIMG_PROFILE
+        if (e->stamps && split) {       // diagnostic builds: 16 uint64 of cycle accounting per item
+            if ((rc = e->reserve(e->dbg, (size_t)items * 128))) return rc;
+            if ((rc = e->hip(hipMemsetAsync(e->dbg.p, 0, (size_t)items * 128, e->stream), "dbg memset"))) return rc;
+            dbg = (uint64_t*)e->dbg.p;
+            e->dbg_count[0] = items;
+        }
+#endif
         if ((rc = e->reserve(e->queue, 64))) return rc;
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
         if ((rc = e->hip(hipMemsetAsync(head, 0, sizeof(uint32_t), e->stream), "queue memset"))) return rc;

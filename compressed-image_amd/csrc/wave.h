@@ -28,6 +28,13 @@
 // ------------------------------------------------------------------------------------------------
 #define CIMG_DEV inline
 #define CIMG_HD inline
+#define CIMG_DEV_NOINLINE inline
+// the workgroup's LDS: in the emulator it is whatever buffer the harness passed in
+#define CIMG_LDS_BASE(passed) (passed)
+typedef uint8_t* cimg_global_u8p;
+#define CIMG_AS_GLOBAL(p) (p)
+typedef volatile uint16_t* cimg_lds_vu16p;
+#define CIMG_AS_LDS_VU16(p) (reinterpret_cast<volatile uint16_t*>(p))
 
 namespace cimg {
 
@@ -93,6 +100,18 @@ template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
 #include <hip/hip_runtime.h>
 #define CIMG_DEV __device__ __forceinline__
 #define CIMG_HD __host__ __device__ __forceinline__
+#define CIMG_DEV_NOINLINE __device__ __forceinline__   /* out-of-line was measured 10 % slower (call + flat pointers) */
+// the workgroup's LDS is always reached through the ONE pointer the kernel derives from its
+// `extern __shared__` array: a second extern symbol would physically alias it while the compiler treats
+// two globals as distinct objects and may reorder accesses between them
+#define CIMG_LDS_BASE(passed) (passed)
+// a pointer parameter of an out-of-line device function is generic (flat); this names it global again
+typedef __attribute__((address_space(1))) uint8_t* cimg_global_u8p;
+#define CIMG_AS_GLOBAL(p) ((cimg_global_u8p)(p))
+// volatile accesses are skipped by the compiler's address-space inference and would become FLAT ops
+// (slow, and not ordered with ds_* ops): LDS pointers that must be volatile carry the address space explicitly
+typedef volatile __attribute__((address_space(3))) uint16_t* cimg_lds_vu16p;
+#define CIMG_AS_LDS_VU16(p) ((cimg_lds_vu16p)(p))
 
 namespace cimg {
 
@@ -148,12 +167,29 @@ template <class T> CIMG_DEV void lane_gather(const LV<T>& x, const LV<int>& idx,
 }
 // one returning device-scope atomic on the queue head (MI355X_MICROARCH.md: 'dequeue', ~0.3-1.1 us)
 CIMG_DEV uint32_t queue_pop(uint32_t* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Clock reads for diagnostics.  s_memtime / s_memrealtime are SMEM ops: they count on lgkmcnt together
+// with LDS reads but return OUT OF ORDER with them, so a counted wait after one no longer says which LDS
+// read is back (a plain __builtin_readcyclecounter() inside the LZ4 loops produced wrong LDS data and
+// wedged the kernel).  The wait therefore lives inside the same asm statement (cdna_hip_programming.md
+// section 7, 'In-kernel stamps').
+CIMG_DEV unsigned long long cimg_cycles()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+CIMG_DEV unsigned long long cimg_realtime()
+{
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 // diagnostic builds only (dbg != nullptr): slot[16*w + 4*which], which = 0..3 = {shader clock, 100 MHz wall clock | hw id}
 CIMG_DEV void debug_stamp(uint64_t* dbg, int w, int which)
 {
     if (dbg == nullptr) return;
-    const uint64_t t = __builtin_amdgcn_s_memtime();
-    const uint64_t r = __builtin_amdgcn_s_memrealtime();
+    const uint64_t t = cimg_cycles();
+    const uint64_t r = cimg_realtime();
     const uint32_t hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
     const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));
     if (__lane_id() == 0) {

@@ -87,7 +87,7 @@ int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, 
     std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
     memcpy(lds.data(), src, (size_t)n);
     int nd = 0;
-    const int r = lz4_encode_wave(lds.data(), lds.data() + round16(n), n, dst, cap, accel, nd);
+    const int r = lz4_encode_wave(lds.data(), 0, round16(n), n, dst, cap, accel, &nd);
     if (need) *need = nd;
     return r;
 }
