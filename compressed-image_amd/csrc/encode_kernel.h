@@ -73,13 +73,13 @@ extern long g_emu_windows, g_emu_matches, g_emu_collisions;   // test-side stati
 
 // -DCIMG_PROFILE (diagnostic builds only): per-item cycle accounting written to EncodeArgs::dbg
 #if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-#define CIMG_PROF_DECL unsigned long long prof_t_ = cimg_cycles(); unsigned long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int prof_cnt_[4] = {0, 0, 0, 0}
+#define CIMG_PROF_DECL unsigned long long prof_t_ = cimg_cycles(); unsigned long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int prof_cnt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #ifndef CIMG_PROFILE_MASK
 #define CIMG_PROFILE_MASK 0xFF
 #endif
 #define CIMG_PROF_LAP(i) do { if ((CIMG_PROFILE_MASK >> (i)) & 1) { const unsigned long long n_ = cimg_cycles(); prof_acc_[i] += n_ - prof_t_; prof_t_ = n_; } } while (0)
 #define CIMG_PROF_COUNT(i) (++prof_cnt_[i])
-#define CIMG_PROF_STORE(dbg, item) do { if (dbg && __lane_id() == 0) { for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + k_] = prof_acc_[k_]; for (int k_ = 0; k_ < 4; k_++) dbg[16 * (size_t)(item) + 8 + k_] = (unsigned long long)prof_cnt_[k_]; } } while (0)
+#define CIMG_PROF_STORE(dbg, item) do { if (dbg && __lane_id() == 0) { for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + k_] = prof_acc_[k_]; for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + 8 + k_] = (unsigned long long)prof_cnt_[k_]; } } while (0)
 #else
 #define CIMG_PROF_DECL
 #define CIMG_PROF_LAP(i) ((void)0)
@@ -95,7 +95,9 @@ CIMG_DEV int skip_prefix(int n) { const int q = n >> 6, r = n & 63; return q * (
 CIMG_DEV void emit_len_ext(cimg_global_u8p out, int pos, int rem)
 {
     const int n255 = rem / 255, last = rem - 255 * n255;
+#ifndef CIMG_EMULATE
 #pragma unroll 1
+#endif
     for (int c = 0; c <= n255; c += 64) {
         FOR_LANES(l) { if (c + l <= n255) out[pos + c + l] = (uint8_t)(c + l < n255 ? 255 : last); }
     }
@@ -103,10 +105,89 @@ CIMG_DEV void emit_len_ext(cimg_global_u8p out, int pos, int rem)
 
 CIMG_DEV void emit_literals(const uint8_t* in, int from, cimg_global_u8p out, int pos, int count)
 {
+#ifndef CIMG_EMULATE
 #pragma unroll 1
+#endif
     for (int c = 0; c < count; c += 64) {
         FOR_LANES(l) { if (c + l < count) out[pos + c + l] = in[from + c + l]; }
     }
+}
+
+CIMG_DEV int div255(int x) { return (int)(((uint64_t)(uint32_t)x * 0x80808081ull) >> 39); }
+
+// Writes the np parked sequences (lane k = k-th sequence) at out[op..) and advances op.  The limited-output
+// checks of LZ4_compress_generic are evaluated for all of them at once: the encoder's result is 0 as soon as
+// ANY check fails and `need` is the maximum of all left-hand sides, so checking late gives the same answer.
+// Returns false when the output does not fit cap.
+CIMG_DEV bool emit_pending(const uint8_t* in, cimg_global_u8p out, int cap, int& op, int& need, int np,
+                           const LV<int>& P_anchor, const LV<int>& P_lit, const LV<int>& P_off, const LV<int>& P_mcode)
+{
+    LV<int> size, start, le, me;
+    FOR_LANES(l) {
+        const int lit = P_lit[l], mc = P_mcode[l];
+        le[l] = lit >= 15 ? div255(lit - 15) + 1 : 0;             // literal-length extension bytes
+        me[l] = mc >= 15 ? div255(mc - 15) + 1 : 0;               // match-length extension bytes
+        size[l] = l < np ? lit + 3 + le[l] + me[l] : 0;
+    }
+    int total;
+    wave_exscan(size, start, total);
+    LV<int> lhs, tokpos, litpos;
+    LV<bool> fail, ext, shortlit, longlit;
+    FOR_LANES(l) {
+        const int lit = P_lit[l], mc = P_mcode[l];
+        const bool act = l < np;
+        tokpos[l] = op + start[l];
+        litpos[l] = tokpos[l] + 1 + le[l];
+        const int lhs1 = tokpos[l] + 1 + lit + 8 + div255(lit);
+        const int lhs2 = litpos[l] + lit + 8 + div255(mc + 240);
+        fail[l] = act && (lhs1 > cap || lhs2 > cap);
+        lhs[l] = act ? imax(lhs1, lhs2) : 0;
+        ext[l] = act && (le[l] > 0 || me[l] > 0);
+        shortlit[l] = act && lit > 0 && lit <= 8;
+        longlit[l] = act && lit > 8;
+    }
+    if (ballot(fail)) return false;
+    need = imax(need, wave_max(lhs));
+    FOR_LANES(l) {
+        if (l < np) {
+            const int lit = P_lit[l], mc = P_mcode[l], off = P_off[l];
+            const int offpos = litpos[l] + lit;
+            out[tokpos[l]] = (uint8_t)(((lit >= 15 ? 15 : lit) << 4) | (mc >= 15 ? 15 : mc));
+            out[offpos] = (uint8_t)(off & 0xFF);
+            out[offpos + 1] = (uint8_t)(off >> 8);
+        }
+    }
+    if (ballot(ext)) {
+        for (int r = 0;; ++r) {
+            LV<bool> more;
+            FOR_LANES(l) {
+                const int lit = P_lit[l], mc = P_mcode[l];
+                const bool act = l < np;
+                if (act && r < le[l]) out[tokpos[l] + 1 + r] = (uint8_t)(r == le[l] - 1 ? lit - 15 - 255 * (le[l] - 1) : 255);
+                if (act && r < me[l]) out[litpos[l] + lit + 2 + r] = (uint8_t)(r == me[l] - 1 ? mc - 15 - 255 * (me[l] - 1) : 255);
+                more[l] = act && (r + 1 < le[l] || r + 1 < me[l]);
+            }
+            if (!ballot(more)) break;
+        }
+    }
+    if (ballot(shortlit)) {
+        for (int r = 0; r < 8; ++r) {                              // short literal runs: one lane per sequence
+            LV<bool> more;
+            FOR_LANES(l) {
+                if (shortlit[l] && r < P_lit[l]) out[litpos[l] + r] = in[P_anchor[l] + r];
+                more[l] = shortlit[l] && r + 1 < P_lit[l];
+            }
+            if (!ballot(more)) break;
+        }
+    }
+    uint64_t longm = ballot(longlit);
+    while (longm) {                                                // long literal runs: the whole wave copies one
+        const int k = ctz64(longm);
+        longm &= longm - 1;
+        emit_literals(in, readlane(P_anchor, k), out, readlane(litpos, k), readlane(P_lit, k));
+    }
+    op += total;
+    return true;
 }
 
 // Bit-exact LZ4_compress_fast(in, out, n, cap, accel) in limited-output mode, byU16 table, by one wave.
@@ -131,12 +212,16 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
     const int s64 = accel << 6;
     const int f64 = skip_prefix(s64);
     int anchor = 0, op = 0, need = 0;
+    // sequences found but not yet written: lane k holds the k-th (anchor, literal count, offset, match code)
+    LV<int> P_anchor, P_lit, P_off, P_mcode;
+    int np = 0;
+    FOR_LANES(l) { P_anchor[l] = 0; P_lit[l] = 0; P_off[l] = 0; P_mcode[l] = 0; }
 
     if (n >= 13) {
         {   // first byte
             LV<uint32_t> v0;
             FOR_LANES(l) { v0[l] = lds_ld32u(in, 0); }
-            FOR_LANES_W(l) { if (l == 0) tab16[lz4_hash(v0[l])] = 0; }
+            FOR_LANES_W(l) { tab16[lz4_hash(v0[l])] = 0; }              // every lane: same slot, same value
         }
         CIMG_PROF_LAP(0);                                  // table clear + first byte
         int sstart = 1;     // search start position
@@ -150,11 +235,12 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             LV<bool> valid;
             LV<uint32_t> v, h, back;
             const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
+            const bool dense = t0 == 0 && s64 == 64;
             FOR_LANES(l) {
                 const int t = t0 + l - pre;                       // probe number, -1 for the pre lane
                 // probe t sits at sstart + (t ? 1 + sum_{u<t-1} ((s64+u)>>6) : 0); the next one is one gap further
-                const int p = t <= 0 ? sstart + t : sstart + 1 + skip_prefix(s64 + t - 1) - f64;
-                const int gap = t <= 0 ? 1 : (s64 + t - 1) >> 6;
+                int p = sstart + t, gap = 1;                      // first window of a search at accel 1: step 1
+                if (!dense && t > 0) { p = sstart + 1 + skip_prefix(s64 + t - 1) - f64; gap = (s64 + t - 1) >> 6; }
                 pos[l] = p;
                 valid[l] = t < 0 || p + gap <= mflimit_p1;
                 v[l] = lds_ld32u(in, valid[l] ? p : 0);
@@ -179,7 +265,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     const int ip0 = sstart - 1;
                     const uint32_t h0 = lz4_hash(v0);
                     const uint32_t bbbb = (v0 & 0xFF) * 0x01010101u;            // v0 == v1 means v0 is four equal bytes
-                    FOR_LANES_W(l) { if (l == 0) tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
+                    FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
                     LV<uint32_t> slot, scan;
                     LV<uint32_t> before;
                     FOR_LANES(l) {
@@ -195,10 +281,10 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     CIMG_STAT(g_emu_matches);
                     if (hit0) {
                         // zero-literal match at the post-match probe; its length depends on the candidate
-                        FOR_LANES_W(l) { if (l == 0) tab16[h0] = (uint16_t)ip0; }
+                        FOR_LANES_W(l) { tab16[h0] = (uint16_t)ip0; }
                         ip = ip0; mp = old0; zero_lit = true;
                     } else {
-                        FOR_LANES_W(l) { if (l == 0) tab16[h0] = (uint16_t)(ip0 + 1); }
+                        FOR_LANES_W(l) { tab16[h0] = (uint16_t)(ip0 + 1); }
                         ip = ip0 + 1; mp = ip0; zero_lit = false; extended = true;
                         backrun = (readlane(before, 0) == (v0 & 0xFF)) ? 1 : 0;      // room is min(ip - anchor, mp) = 1
                         // offset-1 match: it runs to the end of the run (or matchlimit)
@@ -229,8 +315,40 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 }
             }
             if (have_match) { CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0); }   // run path
+            // ---- narrow path ----------------------------------------------------------------------------------
+            // In compressible data the next match is almost always found by the post-match probe or one of the
+            // first probes of the new search.  With pairwise different hashes among those few probes, sequential
+            // LZ4 and "read all slots, then write" agree, so the 64-lane collision machinery is not needed:
+            // slots in one LDS round trip, candidates in a second, writes only for the probes actually consumed.
+            if (!have_match && pre && nv >= 4) {
+                FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
+                LV<uint32_t> h1, h2, h3, old4;
+                lane_prev(h, h1);
+                lane_prev(h1, h2);
+                lane_prev(h2, h3);
+                LV<bool> dup, hit4;
+                FOR_LANES(l) {
+                    old4[l] = tab16[h[l]];
+                    dup[l] = ((l >= 1) & (h[l] == h1[l])) | ((l >= 2) & (h[l] == h2[l])) | ((l >= 3) & (h[l] == h3[l]));
+                }
+                FOR_LANES(l) { hit4[l] = (l < 4) & (lds_ld32u(in, (int)old4[l]) == v[l]); }
+                const uint64_t hm = ballot(hit4);
+                if (hm) {
+                    const int m4 = ctz64(hm);
+                    if (!(ballot(dup) & ((2ull << m4) - 1))) {
+                        FOR_LANES_W(l) { if (l <= m4) tab16[h[l]] = (uint16_t)pos[l]; }
+                        ip = readlane(pos, m4);
+                        mp = (int)readlane(old4, m4);
+                        zero_lit = m4 == 0;
+                        have_match = true;
+                        CIMG_STAT(g_emu_matches);
+                        CIMG_PROF_COUNT(7);
+                    }
+                }
+                CIMG_PROF_LAP(7);
+            }
             if (!have_match) {
-            FOR_LANES_W(l) { if (pre && l == 0) tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
+            if (pre) { FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; } }
             // a lane with the same hash as its left neighbour has that neighbour as candidate
             LV<uint32_t> ph, pv;
             LV<int> ppos;
@@ -301,17 +419,16 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             const int maxc = matchlimit - (ip + 4);
                 LV<bool> eq, stop;
                 LV<int> len;
+                // No guards around the loads: bytes past the plane end are readable (the hash table follows
+                // it in LDS) and lanes past matchlimit are cut by the min with vb, so both directions go out
+                // in ONE LDS round trip.
                 FOR_LANES(l) {
-                    eq[l] = l < room && in[ip - 1 - l] == in[mp - 1 - l];
+                    const int kb = l < room ? l + 1 : 0;
+                    const uint32_t pa = in[ip - kb], pb = in[mp - kb];
                     const int k = 4 * l;
-                    int vb = maxc - k;
-                    vb = vb < 0 ? 0 : (vb > 4 ? 4 : vb);
-                    int ln = 0;
-                    if (vb > 0) {
-                        const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
-                        ln = x ? (int)(__builtin_ctz(x) >> 3) : 4;
-                        if (ln > vb) ln = vb;
-                    }
+                    const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
+                    eq[l] = (l < room) & (pa == pb);
+                    const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
                     len[l] = ln;
                     stop[l] = ln < 4;
                 }
@@ -325,14 +442,8 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     for (;;) {                                    // long match: keep counting, 256 bytes a step
                         FOR_LANES(l) {
                             const int k = mcode + 4 * l;
-                            int vb = maxc - k;
-                            vb = vb < 0 ? 0 : (vb > 4 ? 4 : vb);
-                            int ln = 0;
-                            if (vb > 0) {
-                                const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
-                                ln = x ? (int)(__builtin_ctz(x) >> 3) : 4;
-                                if (ln > vb) ln = vb;
-                            }
+                            const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
+                            const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
                             len[l] = ln;
                             stop[l] = ln < 4;
                         }
@@ -354,44 +465,17 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);               // match extension
             ip -= backrun; mp -= backrun; mcode += backrun;
             const int lit = zero_lit ? 0 : ip - anchor;
-            // ---- budget checks (limited-output rules) -------------------------------------------------------
-            const int tok = op;
-            int q = op + 1;
-            const int lhs1 = q + lit + 8 + lit / 255;
-            if (lhs1 > cap) return 0;
-            need = imax(need, lhs1);
-            if (lit >= 15) q += (lit - 15) / 255 + 1;
-            const int litpos = q;
-            q += lit;
-            const int offpos = q;
-            q += 2;
-            const int lhs2 = q + 6 + (mcode + 240) / 255;
-            if (lhs2 > cap) return 0;
-            need = imax(need, lhs2);
-            // ---- emit ----------------------------------------------------------------------------------------
+            // ---- park the sequence; budget checks and stores happen 64 sequences at a time -------------------
             {
-                const int off = ip - mp;
-                const uint32_t token = (uint32_t)((lit >= 15 ? 15 : lit) << 4) | (uint32_t)(mcode >= 15 ? 15 : mcode);
-                if (lit <= 60 && lit < 15) {
-                    // the common short sequence: token, literals, offset in one store wave
-                    FOR_LANES(l) {
-                        if (l == 0) out[tok] = (uint8_t)token;
-                        else if (l <= lit) out[tok + l] = in[anchor + l - 1];
-                        else if (l == lit + 1) out[offpos] = (uint8_t)(off & 0xFF);
-                        else if (l == lit + 2) out[offpos + 1] = (uint8_t)(off >> 8);
-                    }
-                } else {
-                    FOR_LANES(l) {
-                        if (l == 0) out[tok] = (uint8_t)token;
-                        if (l == 1) out[offpos] = (uint8_t)(off & 0xFF);
-                        if (l == 2) out[offpos + 1] = (uint8_t)(off >> 8);
-                    }
-                    if (lit >= 15) emit_len_ext(out, tok + 1, lit - 15);
-                    emit_literals(in, anchor, out, litpos, lit);
+                const int slot = np;
+                FOR_LANES(l) {
+                    if (l == slot) { P_anchor[l] = anchor; P_lit[l] = lit; P_off[l] = ip - mp; P_mcode[l] = mcode; }
                 }
-                if (mcode >= 15) { emit_len_ext(out, q, mcode - 15); q += (mcode - 15) / 255 + 1; }
+                if (++np == 64) {
+                    if (!emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) return 0;
+                    np = 0;
+                }
             }
-            op = q;
             ip += mcode + 4;
             anchor = ip;
             CIMG_PROF_LAP(5);                                   // budget checks + emit
@@ -401,6 +485,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             pre = 1;
         }
     }
+    if (np && !emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) return 0;
     // ---- last literals ------------------------------------------------------------------------------------
     {
         const int run = n - anchor;

@@ -19,13 +19,14 @@ eng.debug_stamps(True)
 eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
 st = eng.read_stamps(0).astype(np.float64)
 print(fam, "items", len(st))
-names = ["clear+first", "pos+vread", "runpath", "window", "extend", "emit", "lastlit", "-"]
+names = ["clear+first", "pos+vread", "runpath", "window", "extend", "emit", "lastlit", "narrow"]
 total_blocks = len(st) // 2
 for plane, sl in (("plane1 (high byte)", slice(0, total_blocks)), ("plane0 (low byte)", slice(total_blocks, None))):
     s = st[sl]
-    cyc = s[:, :8].mean(axis=0); cnt = s[:, 8:12].mean(axis=0)
+    cyc = s[:, :8].mean(axis=0); cnt = s[:, 8:16].mean(axis=0)
     print(" ", plane, "total cycles %.0f" % cyc.sum(), " counts: runpath %.1f windows %.1f extends %.1f" % (cnt[0], cnt[1], cnt[2]))
     print("    " + "  ".join("%s=%.0f" % (nm, c) for nm, c in zip(names, cyc)))
+    print("    window hits at probe: first(pre/0) %.1f  second %.1f  3rd-8th %.1f  later %.1f   narrow-path hits %.1f" % tuple(cnt[3:8]))
     if cnt[0] > 0: print("    per runpath %.0f cyc" % (cyc[2] / cnt[0]))
     if cnt[1] > 0: print("    per window  %.0f cyc (pos+vread per iteration %.0f)" % (cyc[3] / cnt[1], cyc[1] / (cnt[0] + cnt[1])))
     if cnt[2] > 0: print("    per extend  %.0f cyc, per emit %.0f cyc" % (cyc[4] / cnt[2], cyc[5] / max(cnt[0] + cnt[2] - cnt[0], 1)))
