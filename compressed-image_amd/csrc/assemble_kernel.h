@@ -27,6 +27,8 @@ struct AssembleArgs {
     uint8_t* comp;             // chunks are written at comp + desc.comp_off
     ChunkLayout* layout;       // per chunk
     int32_t uniform_nblocks;   // > 0: every chunk has this many blocks
+    ChunkLayout* layout_host;  // optional second copy of `layout` in pinned host memory (read by the host after the sync)
+    uint32_t* queue;           // optional: the encode work-queue heads (words 0 and 4), zeroed here for the next batch
 };
 
 CIMG_DEV int rec_payload(const StreamRec& r) { return r.kind == REC_RUN ? (r.value > 0 ? 1 : 0) : r.csize; }
@@ -135,7 +137,13 @@ struct LayoutChunk {
                 if (d.destsize >= HEADER_LEN) write_header(d, c, d.flags, 0, 0);
             }
         }
-        FOR_LANES(l) { if (l == 0) a.layout[chunk] = lay; }
+        FOR_LANES(l) {
+            if (l == 0) {
+                a.layout[chunk] = lay;
+                if (a.layout_host) a.layout_host[chunk] = lay;
+                if (a.queue && chunk == 0) { a.queue[0] = 0; a.queue[4] = 0; }
+            }
+        }
     }
 };
 

@@ -199,6 +199,44 @@ CIMG_DEV void lds_fill_bytes(uint8_t* lds, int dst, int len, uint32_t byte)
     }
 }
 
+// dst - src >= 1024 (no overlap inside a 1 KiB step): 16 bytes per lane, aligned 128-bit stores
+CIMG_DEV void lds_copy_huge(uint8_t* lds, int dst, int src, int len)
+{
+    const int head = imin((16 - (dst & 15)) & 15, len);
+    if (head) {
+        LV<uint32_t> t;
+        FOR_LANES(l) { t[l] = lds[src + (l < head ? l : 0)]; }
+        FOR_LANES_W(l) { if (l < head) lds[dst + l] = (uint8_t)t[l]; }
+    }
+    int done = head;
+    while (len - done >= 16) {
+        const int units = imin((len - done) >> 4, 64);
+        LV<u128> t;
+        FOR_LANES(l) {
+            const int sa = src + done + 16 * (l < units ? l : 0);
+            const int a = sa & ~3;
+            const uint32_t sh = (uint32_t)sa & 3u;
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(lds + a);
+            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(lds + a + 4);
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(lds + a + 8);
+            const uint32_t w3 = *reinterpret_cast<const uint32_t*>(lds + a + 12);
+            const uint32_t w4 = *reinterpret_cast<const uint32_t*>(lds + a + 16);
+            t[l].x = alignbyte(w1, w0, sh);
+            t[l].y = alignbyte(w2, w1, sh);
+            t[l].z = alignbyte(w3, w2, sh);
+            t[l].w = alignbyte(w4, w3, sh);
+        }
+        FOR_LANES_W(l) { if (l < units) st128a(lds + dst + done + 16 * l, t[l]); }
+        done += 16 * units;
+    }
+    if (done < len) {
+        const int tail = len - done;
+        LV<uint32_t> t;
+        FOR_LANES(l) { t[l] = lds[src + done + (l < tail ? l : 0)]; }
+        FOR_LANES_W(l) { if (l < tail) lds[dst + done + l] = (uint8_t)t[l]; }
+    }
+}
+
 // t mod m for 0 <= t < 128, 1 <= m < 64 (float reciprocal + one fix-up; exact in this range)
 CIMG_DEV int small_mod(int t, int m, float inv_m)
 {
@@ -209,8 +247,38 @@ CIMG_DEV int small_mod(int t, int m, float inv_m)
     return r;
 }
 
-CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, int lds_limit)
+// a match longer than 64 bytes, any offset >= 1
+CIMG_DEV void lds_copy_match(uint8_t* lds, int dst, int src, int ml)
 {
+    const int offset = dst - src;
+    if (offset >= 1024 && ml >= 512) {
+        lds_copy_huge(lds, dst, src, ml);
+    } else if (offset >= 256) {
+        lds_copy_wide(lds, dst, src, ml);
+    } else if (offset >= 64) {
+        lds_copy_bytes(lds, dst, src, ml);
+    } else if (offset == 1) {
+        LV<uint32_t> t;
+        FOR_LANES(l) { t[l] = lds[src]; }
+        lds_fill_bytes(lds, dst, ml, readlane(t, 0));
+    } else {
+        // overlapping match: byte t of the match equals pattern byte t mod offset
+        const int period = offset * ((63 + offset) / offset);     // smallest multiple of offset >= 64
+        const float inv = fast_rcp((float)offset);
+        for (int c = 0; c < ml; c += 64) {
+            LV<uint32_t> t;
+            FOR_LANES(l) {
+                if (c + l < ml) t[l] = (c == 0) ? lds[src + small_mod(l, offset, inv)] : lds[dst + c + l - period];
+            }
+            FOR_LANES_W(l) { if (c + l < ml) lds[dst + c + l] = (uint8_t)t[l]; }
+        }
+    }
+}
+
+CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, int lds_limit, uint64_t* dbg = nullptr, int item = 0)
+{
+    CIMG_PROF_DECL;
+    (void)dbg; (void)item;
     int ip = cs;
     const int iend = cs + csize;
     int op = base;
@@ -247,6 +315,30 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
         dst = ((d0_ | (d1_ << 32)) >> sh_) | (sh_ ? (d2_ << (64 - sh_)) : 0);                    \
     } while (0)
 
+    // LZ4 length extension: bytes are added up to and including the first one that is not 255.  64 of them
+    // are looked at per LDS round trip (a 12 KiB match carries 48).
+#define CIMG_LENEXT(acc)                                                                         \
+    do {                                                                                         \
+        for (;;) {                                                                               \
+            if (ip >= iend) return ERR_DATA;                                                     \
+            LV<uint32_t> eb_;                                                                    \
+            LV<bool> stop_;                                                                      \
+            FOR_LANES(l) {                                                                       \
+                eb_[l] = lds[imin(ip + l, clampmax)];                                            \
+                stop_[l] = (eb_[l] != 255) | (ip + l >= iend);                                   \
+            }                                                                                    \
+            const int f_ = ctz64(ballot(stop_));                                                 \
+            if (f_ < 64) {                                                                       \
+                if (ip + f_ >= iend) return ERR_DATA;                                            \
+                acc += 255 * f_ + (int)readlane(eb_, f_);                                        \
+                ip += f_ + 1;                                                                    \
+                break;                                                                           \
+            }                                                                                    \
+            acc += 255 * 64;                                                                     \
+            ip += 64;                                                                            \
+        }                                                                                        \
+    } while (0)
+
     for (;;) {
         if (ip >= iend) return ERR_DATA;
         // ---- batch path: parse every "simple" sequence of the next 64 input bytes at once ------------------
@@ -255,14 +347,20 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
         // whole batch are stored with one instruction, matches run in order from three v_readlane each.
         if (iend - ip >= 24) {
             CIMG_RETIRE();
+            CIMG_PROF_LAP(0);                                   // scalar-path work since the last batch
             LV<uint32_t> tb, o0, o1, ex;
-            LV<int> lit_l, nxt_l, len_l, off_l, ml_l;
-            LV<bool> good;
+            LV<int> lit_l, lsrc_l, walk_l, len_l, off_l, ml_l;
+            LV<bool> good, litok;
             FOR_LANES(l) {
                 const int at = ip + l;
                 tb[l] = lds[imin(at, clampmax)];
-                lit_l[l] = (int)(tb[l] >> 4);
-                const int hp = imin(at + 1 + lit_l[l], clampmax);
+                const uint32_t lb = lds[imin(at + 1, clampmax)];     // literal-length byte, meaningful when the nibble is 15
+                const int litn = (int)(tb[l] >> 4);
+                const bool lext = litn == 15;
+                lit_l[l] = lext ? 15 + (int)lb : litn;
+                litok[l] = !lext | (lb < 255);
+                lsrc_l[l] = l + (lext ? 2 : 1);                      // window offset of the first literal
+                const int hp = imin(ip + lsrc_l[l] + lit_l[l], clampmax);
                 o0[l] = lds[hp];
                 o1[l] = lds[hp + 1];
                 ex[l] = lds[hp + 2];
@@ -272,26 +370,51 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                 const bool has_ext = mln == 15;
                 off_l[l] = (int)(o0[l] | (o1[l] << 8));
                 ml_l[l] = mln + 4 + (has_ext ? (int)ex[l] : 0);
-                nxt_l[l] = l + 1 + lit_l[l] + 2 + (has_ext ? 1 : 0);
+                const int lend = lsrc_l[l] + lit_l[l];                // window offset just past the literals
+                const int nxt = lend + 2 + (has_ext ? 1 : 0);
+                // literals that do not sit inside the window are copied LDS -> LDS, which is done for the LAST
+                // token of a batch only: such a token ends the chain walk (flagged by +1024)
+                walk_l[l] = nxt + ((lit_l[l] >= 15) | (lend > 64) ? 1024 : 0);
                 len_l[l] = lit_l[l] + ml_l[l];
-                // whole header inside the window, a following token exists, lengths need no more bytes
-                good[l] = lit_l[l] < 15 && (!has_ext || ex[l] < 255) && nxt_l[l] <= 64 && ip + nxt_l[l] < iend && off_l[l] != 0;
+                // lengths need no more bytes, a following token exists
+                good[l] = litok[l] & (!has_ext | (ex[l] < 255)) & (ip + nxt < iend) & (off_l[l] != 0);
             }
             const uint64_t goodmask = ballot(good);
+            CIMG_PROF_LAP(1);                                   // per-lane header parse
+            // the real token chain: a scalar walk over the per-lane "next token" answers
             uint64_t tokens = 0;
-            int s = 0, acc = 0;
-            LV<int> opos;
-            FOR_LANES(l) { opos[l] = 0; }
+            int s = 0;
             while (s < 64 && ((goodmask >> s) & 1)) {
-                const int ln = readlane(len_l, s);
-                if (acc + ln > oend - op) break;
-                writelane(opos, s, acc);
                 tokens |= 1ull << s;
-                acc += ln;
-                s = readlane(nxt_l, s);
+                s = readlane(walk_l, s);
+            }
+            int biglast = 0;
+            if (s >= 1024) { s -= 1024; biglast = 1; }
+            CIMG_PROF_LAP(2);                                   // token chain walk
+            // output position of every token: prefix sum of the sequence lengths over the token lanes
+            LV<int> tlen, opos;
+            LV<bool> istok;
+            FOR_LANES(l) {
+                istok[l] = (tokens >> l) & 1;
+                tlen[l] = istok[l] ? len_l[l] : 0;
+            }
+            int acc;
+            wave_exscan(tlen, opos, acc);
+            if (acc > oend - op) {                                 // cut the batch at the first sequence that does not fit
+                const int room = oend - op;
+                LV<bool> over;
+                FOR_LANES(l) { over[l] = istok[l] & (opos[l] + tlen[l] > room); }
+                const int f = ctz64(ballot(over));
+                tokens &= (1ull << f) - 1;
+                s = f;
+                biglast = 0;
+                acc = readlane(opos, f);
+                FOR_LANES(l) { istok[l] = (tokens >> l) & 1; }
             }
             if (tokens) {
                 // literals: lane j belongs to the last token at or before j - 1
+                const int tlast = 63 - (int)__builtin_clzll(tokens);
+                const int litlim = biglast ? tlast : imin(s, 64);
                 LV<int> owner;
                 LV<bool> is_lit;
                 FOR_LANES(l) {
@@ -304,52 +427,46 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                 lane_gather(opos, owner, own_pos);
                 FOR_LANES_W(l) {
                     const int k = l - owner[l] - 1;
-                    if (is_lit[l] && k < own_lit[l] && l < s) lds[op + own_pos[l] + k] = (uint8_t)tb[l];
+                    if (is_lit[l] & (k < own_lit[l]) & (l < litlim)) lds[op + own_pos[l] + k] = (uint8_t)tb[l];
                 }
-                // matches, in order
-                int bad = 0;
+                if (biglast) lds_copy_bytes(lds, op + readlane(opos, tlast), ip + readlane(lsrc_l, tlast), readlane(lit_l, tlast));
+                CIMG_PROF_LAP(3);                               // positions + literals
+                // matches, in order; destination and source of every match are worked out for all tokens at once
+                LV<int> dstv, srcv;
+                LV<bool> badv;
+                FOR_LANES(l) {
+                    dstv[l] = op + opos[l] + lit_l[l];
+                    srcv[l] = dstv[l] - off_l[l];
+                    badv[l] = istok[l] & (srcv[l] < base);
+                }
+                if (ballot(badv)) return ERR_DATA;
                 uint64_t todo = tokens;
                 while (todo) {
                     const int t = ctz64(todo);
                     todo &= todo - 1;
-                    const int dst = op + readlane(opos, t) + readlane(lit_l, t);
-                    const int offset = readlane(off_l, t);
+                    CIMG_PROF_COUNT(0);
+                    const int dst = readlane(dstv, t);
+                    const int src = readlane(srcv, t);
                     const int ml = readlane(ml_l, t);
-                    const int src = dst - offset;
-                    if (src < base) { bad = 1; break; }
-                    CIMG_RETIRE();
+                    const int offset = dst - src;
                     if (ml <= 64) {
+                        LV<uint32_t> mv;
                         if (offset >= ml) {
-                            FOR_LANES(l) { pend[l] = lds[src + (l < ml ? l : 0)]; }
+                            FOR_LANES(l) { mv[l] = lds[src + (l < ml ? l : 0)]; }
                         } else if (offset == 1) {
-                            FOR_LANES(l) { pend[l] = lds[src]; }
+                            FOR_LANES(l) { mv[l] = lds[src]; }
                         } else {
-                            const float inv = 1.0f / (float)offset;
-                            FOR_LANES(l) { pend[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
+                            const float inv = fast_rcp((float)offset);
+                            FOR_LANES(l) { mv[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
                         }
-                        pend_dst = dst;
-                        pend_len = ml;
-                    } else if (offset >= 256) {
-                        lds_copy_wide(lds, dst, src, ml);
-                    } else if (offset >= 64) {
-                        lds_copy_bytes(lds, dst, src, ml);
-                    } else if (offset == 1) {
-                        LV<uint32_t> tt;
-                        FOR_LANES(l) { tt[l] = lds[src]; }
-                        lds_fill_bytes(lds, dst, ml, readlane(tt, 0));
+                        FOR_LANES_W(l) { if (l < ml) lds[dst + l] = (uint8_t)mv[l]; }
                     } else {
-                        const int period = offset * ((63 + offset) / offset);
-                        const float inv = 1.0f / (float)offset;
-                        for (int c = 0; c < ml; c += 64) {
-                            LV<uint32_t> tt;
-                            FOR_LANES(l) { if (c + l < ml) tt[l] = (c == 0) ? lds[src + small_mod(l, offset, inv)] : lds[dst + c + l - period]; }
-                            FOR_LANES_W(l) { if (c + l < ml) lds[dst + c + l] = (uint8_t)tt[l]; }
-                        }
+                        lds_copy_match(lds, dst, src, ml);
                     }
                 }
-                if (bad) return ERR_DATA;
                 ip += s;
                 op += acc;
+                CIMG_PROF_LAP(4); CIMG_PROF_COUNT(1);           // matches of the batch
                 continue;
             }
         }
@@ -371,15 +488,7 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                     // long match: more length bytes follow
                     ip += hdr + 1;
                     ml += 255;
-                    uint32_t b;
-                    do {
-                        if (ip >= iend) return ERR_DATA;
-                        uint64_t e;
-                        CIMG_FETCH8(e, ip);
-                        b = (uint32_t)(e & 0xFF);
-                        ip++;
-                        ml += (int)b;
-                    } while (b == 255);
+                    CIMG_LENEXT(ml);
                     extra = -1;
                 } else {
                     ml += extra;
@@ -398,15 +507,7 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
             CIMG_RETIRE();
             ip++;
             if (lit == 15) {
-                uint32_t b;
-                do {
-                    if (ip >= iend) return ERR_DATA;
-                    uint64_t e;
-                    CIMG_FETCH8(e, ip);
-                    b = (uint32_t)(e & 0xFF);
-                    ip++;
-                    lit += (int)b;
-                } while (b == 255);
+                CIMG_LENEXT(lit);
             }
             if (lit > iend - ip || lit > oend - op) return ERR_DATA;
             if (lit > 0) {
@@ -421,20 +522,15 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
             offset = (int)(e & 0xFFFF);
             ip += 2;
             if (ext) {
-                uint32_t b;
-                do {
-                    if (ip >= iend) return ERR_DATA;
-                    CIMG_FETCH8(e, ip);
-                    b = (uint32_t)(e & 0xFF);
-                    ip++;
-                    ml += (int)b;
-                } while (b == 255);
+                CIMG_LENEXT(ml);
             }
         }
         if (ip > iend) return ERR_DATA;
         if (offset == 0 || offset > op - base) return ERR_DATA;
         ml += 4;
         if (ml > oend - op) return ERR_DATA;
+        CIMG_PROF_COUNT(2);
+        if (ml > 64) CIMG_PROF_COUNT(3);
         const int src = op - offset;
         if (ml <= 64) {
             // request the source bytes now, store them after the next header has been parsed
@@ -443,35 +539,21 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
             } else if (offset == 1) {
                 FOR_LANES(l) { pend[l] = lds[src]; }
             } else {
-                const float inv = 1.0f / (float)offset;
+                const float inv = fast_rcp((float)offset);
                 FOR_LANES(l) { pend[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
             }
             pend_dst = op;
             pend_len = ml;
-        } else if (offset >= 256 && ml >= 128) {
-            lds_copy_wide(lds, op, src, ml);
-        } else if (offset >= 64) {
-            lds_copy_bytes(lds, op, src, ml);
-        } else if (offset == 1) {
-            LV<uint32_t> t;
-            FOR_LANES(l) { t[l] = lds[src]; }
-            lds_fill_bytes(lds, op, ml, readlane(t, 0));
         } else {
-            // overlapping match: byte t of the match equals pattern byte t mod offset
-            const int period = offset * ((63 + offset) / offset);     // smallest multiple of offset >= 64
-            const float inv = 1.0f / (float)offset;
-            for (int c = 0; c < ml; c += 64) {
-                LV<uint32_t> t;
-                FOR_LANES(l) {
-                    if (c + l < ml) t[l] = (c == 0) ? lds[src + small_mod(l, offset, inv)] : lds[op + c + l - period];
-                }
-                FOR_LANES_W(l) { if (c + l < ml) lds[op + c + l] = (uint8_t)t[l]; }
-            }
+            lds_copy_match(lds, op, src, ml);
         }
         op += ml;
     }
     CIMG_RETIRE();
+    CIMG_PROF_LAP(0);
+    CIMG_PROF_STORE(dbg, item);
 #undef CIMG_FETCH8
+#undef CIMG_LENEXT
 #undef CIMG_RETIRE
     return op == oend ? 0 : ERR_DATA;
 }
@@ -568,7 +650,7 @@ struct DecodeBlock {
                 } else {
                     const int park = base + rs - round16(cs);
                     wave_copy_g2l(c + pos, lds, park, cs);
-                    const int rc = lz4_decode_wave(lds, base, neblock, park, cs, a.lds_bytes);
+                    const int rc = lz4_decode_wave(lds, base, neblock, park, cs, a.lds_bytes, a.dbg, b);
                     if (rc < 0) fail(rc);
                 }
             }

@@ -71,22 +71,6 @@ extern long g_emu_windows, g_emu_matches, g_emu_collisions;   // test-side stati
 #define CIMG_STAT(x) ((void)0)
 #endif
 
-// -DCIMG_PROFILE (diagnostic builds only): per-item cycle accounting written to EncodeArgs::dbg
-#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-#define CIMG_PROF_DECL unsigned long long prof_t_ = cimg_cycles(); unsigned long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int prof_cnt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#ifndef CIMG_PROFILE_MASK
-#define CIMG_PROFILE_MASK 0xFF
-#endif
-#define CIMG_PROF_LAP(i) do { if ((CIMG_PROFILE_MASK >> (i)) & 1) { const unsigned long long n_ = cimg_cycles(); prof_acc_[i] += n_ - prof_t_; prof_t_ = n_; } } while (0)
-#define CIMG_PROF_COUNT(i) (++prof_cnt_[i])
-#define CIMG_PROF_STORE(dbg, item) do { if (dbg && __lane_id() == 0) { for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + k_] = prof_acc_[k_]; for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + 8 + k_] = (unsigned long long)prof_cnt_[k_]; } } while (0)
-#else
-#define CIMG_PROF_DECL
-#define CIMG_PROF_LAP(i) ((void)0)
-#define CIMG_PROF_COUNT(i) ((void)0)
-#define CIMG_PROF_STORE(dbg, item) ((void)0)
-#endif
-
 CIMG_DEV uint32_t lz4_hash(uint32_t v) { return (v * 2654435761u) >> 19; }
 // sum_{x=0}^{n-1} (x >> 6)
 CIMG_DEV int skip_prefix(int n) { const int q = n >> 6, r = n & 63; return q * (32 * (q - 1) + r); }

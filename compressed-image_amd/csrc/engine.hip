@@ -44,6 +44,12 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs 
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     DecodeBlock blk(a, lds, (int)blockIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef CIMG_PROFILE
+    // diagnostic builds: the 16 uint64 per workgroup carry the LZ4 decoder's cycle laps instead of phase stamps
+    blk.phase_a(wave);
+    __syncthreads();
+    blk.phase_b(wave);
+#else
     if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
     blk.phase_a(wave);
     if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 1);       // stream 0 staged
@@ -51,6 +57,7 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs 
     __syncthreads();
     blk.phase_b(wave);
     if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
+#endif
 }
 
 // ====================================================================================================
@@ -77,7 +84,11 @@ struct EventPair {
 struct cimg_engine {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf descs, recs, layout, scratch, status, stage_raw, stage_comp, dbg, queue;
+    DevBuf descs_enc, descs_dec, recs, layout, scratch, stage_raw, stage_comp, dbg, queue;
+    // chunk descriptors last uploaded for encode / decode: a batch with the same geometry as the previous one
+    // (the steady state of an image pipeline) skips the upload
+    std::vector<uint8_t> shadow_enc, shadow_dec;
+    bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
     int num_cus = 256;
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
     int enc_wgs_lds[2] = {-1, -1};
@@ -116,6 +127,29 @@ struct cimg_engine {
         int rc = hip(hipMalloc(&b.p, want), "hipMalloc");
         if (rc) return rc;
         b.cap = want;
+        return 0;
+    }
+    // kernels write their small results (chunk sizes, status words) straight into pinned host memory:
+    // no D2H copy node between the last kernel and the synchronize
+    template <class T> int device_alias(PinBuf& b, T** out)
+    {
+        void* d = nullptr;
+        int rc = hip(hipHostGetDevicePointer(&d, b.p, 0), "hipHostGetDevicePointer");
+        *out = (T*)d;
+        return rc;
+    }
+    // descriptors -> device, unless the device copy already holds exactly these bytes
+    int upload_descs(DevBuf& dev, std::vector<uint8_t>& shadow, const void* src, size_t bytes)
+    {
+        if (shadow.size() == bytes && dev.p && memcmp(shadow.data(), src, bytes) == 0) return 0;
+        int rc;
+        shadow.clear();
+        if ((rc = reserve(dev, bytes))) return rc;
+        if ((rc = reserve(h_descs, bytes))) return rc;
+        memcpy(h_descs.p, src, bytes);
+        // every batch call ends with a stream synchronize, so h_descs is free again before the next upload
+        if ((rc = hip(hipMemcpyAsync(dev.p, h_descs.p, bytes, hipMemcpyHostToDevice, stream), "descs H2D"))) return rc;
+        shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
         return 0;
     }
     int reserve(PinBuf& b, size_t bytes)
@@ -239,7 +273,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs, &e->recs, &e->layout, &e->scratch, &e->status, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_out})
         if (b->p) (void)hipHostFree(b->p);
@@ -321,14 +355,19 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
     if (rc < 0) return e->fail(rc, "compress batch rejected by the planner (code %d): codec %d / filter pipeline / block size %d not available on the GPU path",
                                rc, p->compcode, p->blocksize);
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
-    if ((rc = e->reserve(e->descs, desc_bytes))) return rc;
-    if ((rc = e->reserve(e->h_descs, desc_bytes))) return rc;
+    if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, plan.descs.data(), desc_bytes))) return rc;
     if ((rc = e->reserve(e->recs, sizeof(StreamRec) * (size_t)plan.total_blocks * plan.cp.streams_per_block))) return rc;
     if ((rc = e->reserve(e->layout, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
     if ((rc = e->reserve(e->h_out, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
     if ((rc = e->reserve(e->scratch, (size_t)plan.total_blocks * plan.cp.slot_bytes + 64))) return rc;
-    memcpy(e->h_descs.p, plan.descs.data(), desc_bytes);
-    if ((rc = e->hip(hipMemcpyAsync(e->descs.p, e->h_descs.p, desc_bytes, hipMemcpyHostToDevice, e->stream), "descs H2D"))) return rc;
+    ChunkLayout* lay_host = nullptr;
+    if ((rc = e->device_alias(e->h_out, &lay_host))) return rc;
+    if (!e->queue.p) e->queue_clean = false;
+    if ((rc = e->reserve(e->queue, 64))) return rc;
+    if (!e->queue_clean) {
+        if ((rc = e->hip(hipMemsetAsync(e->queue.p, 0, 64, e->stream), "queue memset"))) return rc;
+    }
+    e->queue_clean = false;
 
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
@@ -343,10 +382,8 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
             e->dbg_count[0] = items;
         }
 #endif
-        if ((rc = e->reserve(e->queue, 64))) return rc;
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
-        if ((rc = e->hip(hipMemsetAsync(head, 0, sizeof(uint32_t), e->stream), "queue memset"))) return rc;
-        EncodeArgs ea{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
+        EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks};
         if ((rc = e->allow_lds(cimg_encode_streams, 0, lds_bytes))) return rc;
         // persistent workgroups: as many as are resident at once, never more than there are items
@@ -360,11 +397,12 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
         const int grid = std::min(items, e->enc_wgs_per_cu[split] * e->num_cus);
         if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_streams, ea, grid, 64, lds_bytes))) return rc;
     }
-    AssembleArgs aa{(const ChunkDesc*)e->descs.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
-                    (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks};
+    AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
+                    (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks,
+                    lay_host, (uint32_t*)e->queue.p};
     if ((rc = e->launch(CIMG_K_LAYOUT, cimg_layout_chunks, aa, nchunks, 64, 0))) return rc;
+    e->queue_clean = true;                        // chunk 0's layout wave zeroes both queue heads for the next batch
     if ((rc = e->launch(CIMG_K_EMIT, cimg_emit_blocks, aa, plan.total_blocks, 256, 0))) return rc;
-    if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->layout.p, sizeof(ChunkLayout) * (size_t)nchunks, hipMemcpyDeviceToHost, e->stream), "layout D2H"))) return rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
     const ChunkLayout* lay = (const ChunkLayout*)e->h_out.p;
     for (int i = 0; i < nchunks; i++) cbytes[i] = lay[i].cbytes;
@@ -383,13 +421,11 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     if (rc < 0) return e->fail(rc, "decompress batch rejected by the planner (code %d)", rc);
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
     const size_t st_bytes = sizeof(int32_t) * (size_t)nchunks;
-    if ((rc = e->reserve(e->descs, desc_bytes))) return rc;
-    if ((rc = e->reserve(e->h_descs, desc_bytes))) return rc;
-    if ((rc = e->reserve(e->status, st_bytes))) return rc;
+    if ((rc = e->upload_descs(e->descs_dec, e->shadow_dec, plan.descs.data(), desc_bytes))) return rc;
     if ((rc = e->reserve(e->h_out, st_bytes))) return rc;
-    memcpy(e->h_descs.p, plan.descs.data(), desc_bytes);
-    if ((rc = e->hip(hipMemcpyAsync(e->descs.p, e->h_descs.p, desc_bytes, hipMemcpyHostToDevice, e->stream), "descs H2D"))) return rc;
-    if ((rc = e->hip(hipMemsetAsync(e->status.p, 0, st_bytes, e->stream), "status memset"))) return rc;
+    int32_t* st_dev = nullptr;                    // the status words live in pinned host memory; only failing blocks write
+    if ((rc = e->device_alias(e->h_out, &st_dev))) return rc;
+    memset(e->h_out.p, 0, st_bytes);
     uint64_t* dbg = nullptr;
     if (e->stamps) {
         if ((rc = e->reserve(e->dbg, (size_t)plan.total_blocks * 128))) return rc;
@@ -397,10 +433,9 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
         dbg = (uint64_t*)e->dbg.p;
         e->dbg_count[1] = plan.total_blocks;
     }
-    DecodeArgs da{(const ChunkDesc*)e->descs.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, (int32_t*)e->status.p, plan.lds_bytes, dbg, plan.uniform_nblocks};
+    DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, dbg, plan.uniform_nblocks};
     if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
     if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
-    if ((rc = e->hip(hipMemcpyAsync(e->h_out.p, e->status.p, st_bytes, hipMemcpyDeviceToHost, e->stream), "status D2H"))) return rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
     const int32_t* st = (const int32_t*)e->h_out.p;
     int first = 0;

@@ -73,6 +73,7 @@ inline void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
     for (int l = 0; l < 64; ++l) { out.v[l] = run; run += x.v[l]; }
     total = run;
 }
+inline float fast_rcp(float x) { return 1.0f / x; }
 inline int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
 inline void debug_stamp(uint64_t*, int, int) {}
 template <class T> inline void writelane(LV<T>& x, int lane, T value) { x.v[lane & 63] = value; }
@@ -135,18 +136,22 @@ CIMG_DEV uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstl
 CIMG_DEV int ctz64(uint64_t m) { return m ? (int)__builtin_ctzll(m) : 64; }
 CIMG_DEV int popc64(uint64_t m) { return (int)__builtin_popcountll(m); }
 CIMG_DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+// exclusive prefix sum across the wave: the DPP scan ladder (row_shr 1/2/4/8, row_bcast 15/31) -- six VALU
+// adds and no trip through the LDS crossbar (a __shfl_up ladder costs six ds_bpermute round trips)
 CIMG_DEV void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
 {
     int v = x.v;
-    const int lane = (int)__lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(v, d);
-        if (lane >= d) v += n;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
     total = __builtin_amdgcn_readlane(v, 63);
     out.v = v - x.v;
 }
+// v_rcp_f32: one instruction, 1 ulp (callers fix the quotient up)
+CIMG_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 CIMG_DEV int wave_max(const LV<int>& x)
 {
     int v = x.v;
@@ -212,6 +217,22 @@ template <class T> CIMG_DEV void lane_prev(const LV<T>& x, LV<T>& out)
 }
 
 }  // namespace cimg
+#endif
+
+// -DCIMG_PROFILE (diagnostic builds only): per-item cycle accounting written to the kernel's dbg buffer (16 uint64 per item)
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+#define CIMG_PROF_DECL unsigned long long prof_t_ = cimg_cycles(); unsigned long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int prof_cnt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#ifndef CIMG_PROFILE_MASK
+#define CIMG_PROFILE_MASK 0xFF
+#endif
+#define CIMG_PROF_LAP(i) do { if ((CIMG_PROFILE_MASK >> (i)) & 1) { const unsigned long long n_ = cimg_cycles(); prof_acc_[i] += n_ - prof_t_; prof_t_ = n_; } } while (0)
+#define CIMG_PROF_COUNT(i) (++prof_cnt_[i])
+#define CIMG_PROF_STORE(dbg, item) do { if (dbg && __lane_id() == 0) { for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + k_] = prof_acc_[k_]; for (int k_ = 0; k_ < 8; k_++) dbg[16 * (size_t)(item) + 8 + k_] = (unsigned long long)prof_cnt_[k_]; } } while (0)
+#else
+#define CIMG_PROF_DECL
+#define CIMG_PROF_LAP(i) ((void)0)
+#define CIMG_PROF_COUNT(i) ((void)0)
+#define CIMG_PROF_STORE(dbg, item) ((void)0)
 #endif
 
 namespace cimg {
