@@ -75,6 +75,32 @@ def cpu_baseline(raw_channels, budget_s=12.0):
                       f"({avail} hardware threads visible)"}
 
 
+# HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KiB), which cannot be collected
+# from inside this process: the committed per-launch averages of the same workload are reported instead
+# (profiles/tools/collect.sh makes them).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the
+# bytes of 16-B-per-lane streaming reads -- the decoder stages compressed bytes that way (x2); the encoder's strided
+# byte-plane gather is calibrated against its known read volume (every raw byte exactly once: factor 1).
+PMC_FILES = ("final_pmc_per_launch.json", "mid_pmc_per_launch.json")
+FETCH_FACTOR = {"cimg_encode_streams": 1.0, "cimg_decode_blocks": 2.0}
+
+
+def pmc_traffic(kernel):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in PMC_FILES:
+        path = os.path.join(here, "profiles", "r01", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                c = json.load(f).get(kernel)
+            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return int((c["FETCH_SIZE"] * FETCH_FACTOR.get(kernel, 1.0) + c["WRITE_SIZE"]) * 1024), "profiles/r01/" + name
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +208,8 @@ def main():
         dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = algo[dom] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         dec_avg_s = ktimes[hip.K_DECODE][0] / max(ktimes[hip.K_DECODE][1], 1) * 1e-3
+        traffic, traffic_src = pmc_traffic(hip.KERNELS[dom]) if args.family == "tiled" else (None, None)
+        dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE]) if args.family == "tiled" else (None, None)
         out = {
             "metric": "compress+decompress GB/s (uncompressed side)",
             "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3),
@@ -198,12 +226,12 @@ def main():
                        "roundtrip_GBps": round(world * args.steps * N / elapsed / 1e9, 3),
                        "parallelism": f"chunks sharded by rank x{world}, no data-path collective"},
             "roofline": {"kernel": hip.KERNELS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_us": round(dom_avg_s * 1e6, 2)},
             "roofline_decode": {"kernel": hip.KERNELS[hip.K_DECODE], "bound": "hbm",
                                 "achieved": round((C + N) / dec_avg_s / 1e9, 1) if dec_avg_s > 0 else None,
                                 "output_side": round(N / dec_avg_s / 1e9, 1) if dec_avg_s > 0 else None,
-                                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": dec_traffic,
                                 "frac": round((C + N) / dec_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if dec_avg_s > 0 else None},
             "kernels": kernels,
         }
