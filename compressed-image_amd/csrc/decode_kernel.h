@@ -88,7 +88,16 @@ CIMG_DEV int find_chunk(const ChunkDesc* descs, int nchunks, int b, int uniform_
 CIMG_DEV void wave_copy_g2l(const uint8_t* g, uint8_t* lds, int off, int nbytes)
 {
     const int units = nbytes >> 4;
-    for (int u0 = 0; u0 < units; u0 += 256) {
+    constexpr int DEPTH = 8;                      // loads in flight per lane before the first LDS store
+    int u0 = 0;
+    for (; u0 + 64 * DEPTH <= units; u0 += 64 * DEPTH) {
+        LV<u128> t[DEPTH];
+        CIMG_UNROLL
+        for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { t[k][l] = ld128u(g + 16 * (u0 + 64 * k + l)); } }
+        CIMG_UNROLL
+        for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { st128a(lds + off + 16 * (u0 + 64 * k + l), t[k][l]); } }
+    }
+    for (; u0 < units; u0 += 256) {
         LV<u128> t0, t1, t2, t3;
         FOR_LANES(l) {
             const int u = u0 + l;

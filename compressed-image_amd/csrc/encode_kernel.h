@@ -220,18 +220,33 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             LV<uint32_t> v, h, back;
             const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
             const bool dense = t0 == 0 && s64 == 64;
-            FOR_LANES(l) {
-                const int t = t0 + l - pre;                       // probe number, -1 for the pre lane
-                // probe t sits at sstart + (t ? 1 + sum_{u<t-1} ((s64+u)>>6) : 0); the next one is one gap further
-                int p = sstart + t, gap = 1;                      // first window of a search at accel 1: step 1
-                if (!dense && t > 0) { p = sstart + 1 + skip_prefix(s64 + t - 1) - f64; gap = (s64 + t - 1) >> 6; }
-                pos[l] = p;
-                valid[l] = t < 0 || p + gap <= mflimit_p1;
-                v[l] = lds_ld32u(in, valid[l] ? p : 0);
-                h[l] = lz4_hash(v[l]);
-                back[l] = lds_ld32u(in, backpos);
+            int nv;                                               // valid lanes are a prefix
+            if (dense) {
+                // first window of a search at acceleration 1 (every window right after a match): probe t sits at
+                // sstart + t with gap 1, so the valid prefix is known without looking at the lanes
+                const int first = sstart - pre;
+                nv = imin(64, pre + imax(mflimit_p1 - sstart, 0));    // the pre lane always; probe t while sstart + t + 1 <= mflimit_p1
+                FOR_LANES(l) {
+                    pos[l] = first + l;
+                    valid[l] = l < nv;
+                    v[l] = lds_ld32u(in, l < nv ? first + l : 0);
+                    h[l] = lz4_hash(v[l]);
+                    back[l] = lds_ld32u(in, backpos);
+                }
+            } else {
+                FOR_LANES(l) {
+                    const int t = t0 + l - pre;                   // probe number, -1 for the pre lane
+                    // probe t sits at sstart + (t ? 1 + sum_{u<t-1} ((s64+u)>>6) : 0); the next one is one gap further
+                    int p = sstart + t, gap = 1;
+                    if (t > 0) { p = sstart + 1 + skip_prefix(s64 + t - 1) - f64; gap = (s64 + t - 1) >> 6; }
+                    pos[l] = p;
+                    valid[l] = t < 0 || p + gap <= mflimit_p1;
+                    v[l] = lds_ld32u(in, valid[l] ? p : 0);
+                    h[l] = lz4_hash(v[l]);
+                    back[l] = lds_ld32u(in, backpos);
+                }
+                nv = popc64(ballot(valid));
             }
-            const int nv = popc64(ballot(valid));                 // valid lanes are a prefix
             CIMG_PROF_LAP(1);                                   // positions + v read
             if (nv == 0) break;                                   // -> last literals
             CIMG_STAT(g_emu_windows);
@@ -264,6 +279,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     have_match = true;
                     CIMG_STAT(g_emu_matches);
                     if (hit0) {
+                        CIMG_PROF_COUNT(5);
                         // zero-literal match at the post-match probe; its length depends on the candidate
                         FOR_LANES_W(l) { tab16[h0] = (uint16_t)ip0; }
                         ip = ip0; mp = old0; zero_lit = true;
@@ -399,6 +415,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
 
             // ---- a match at ip with candidate mp: extend both ways with one LDS round trip ---------------------
             if (!extended) {
+            CIMG_PROF_COUNT(3);
             const int room = zero_lit ? 0 : imin(ip - anchor, mp);
             const int maxc = matchlimit - (ip + 4);
                 LV<bool> eq, stop;
@@ -424,6 +441,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 } else {
                     mcode = 256;
                     for (;;) {                                    // long match: keep counting, 256 bytes a step
+                        CIMG_PROF_COUNT(4);
                         FOR_LANES(l) {
                             const int k = mcode + 4 * l;
                             const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
@@ -456,7 +474,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     if (l == slot) { P_anchor[l] = anchor; P_lit[l] = lit; P_off[l] = ip - mp; P_mcode[l] = mcode; }
                 }
                 if (++np == 64) {
-                    if (!emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) return 0;
+                    if (!emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return 0; }
                     np = 0;
                 }
             }
@@ -469,12 +487,12 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             pre = 1;
         }
     }
-    if (np && !emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) return 0;
+    if (np && !emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return 0; }
     // ---- last literals ------------------------------------------------------------------------------------
     {
         const int run = n - anchor;
         const int lhs = op + run + 1 + (run + 240) / 255;
-        if (lhs > cap) return 0;
+        if (lhs > cap) { CIMG_PROF_LAP(6); CIMG_PROF_STORE(dbg, item); return 0; }
         need = imax(need, lhs);
         const uint32_t token = (uint32_t)((run >= 15 ? 15 : run) << 4);
         FOR_LANES(l) { if (l == 0) out[op] = (uint8_t)token; }
@@ -546,43 +564,60 @@ struct EncodeStream {
             return;
         }
         const int units = bsize >> 4;                    // 16 source bytes = 16/ts plane bytes
+        // A single wave hides HBM latency only through loads in flight: 16 x 16 B per lane are requested
+        // before the first is used (a 32 KiB block is two such rounds instead of eight rounds of four).
+        constexpr int DEPTH = 16;
         if (ts == 2) {
             const uint32_t sel = s ? 0x07050301u : 0x06040200u;
-            for (int u0 = 0; u0 < units; u0 += 256) {
-                LV<u128> x0, x1, x2, x3;
-                FOR_LANES(l) {
-                    const int u = u0 + l;
-                    if (u < units) x0[l] = ld128u(src + 16 * u);
-                    if (u + 64 < units) x1[l] = ld128u(src + 16 * (u + 64));
-                    if (u + 128 < units) x2[l] = ld128u(src + 16 * (u + 128));
-                    if (u + 192 < units) x3[l] = ld128u(src + 16 * (u + 192));
+            int u0 = 0;
+            for (; u0 + 64 * DEPTH <= units; u0 += 64 * DEPTH) {
+                LV<u128> x[DEPTH];
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { x[k][l] = ld128u(src + 16 * (u0 + 64 * k + l)); } }
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) {
+                    FOR_LANES(l) {
+                        uint32_t* d = reinterpret_cast<uint32_t*>(lds + 8 * (u0 + 64 * k + l));
+                        d[0] = byte_perm(x[k][l].y, x[k][l].x, sel);
+                        d[1] = byte_perm(x[k][l].w, x[k][l].z, sel);
+                    }
                 }
+            }
+            for (; u0 < units; u0 += 64) {
                 FOR_LANES(l) {
                     const int u = u0 + l;
-                    #define CIMG_PUT2(X, U) if ((U) < units) { uint32_t* d = reinterpret_cast<uint32_t*>(lds + 8 * (U)); \
-                        d[0] = byte_perm(X.y, X.x, sel); d[1] = byte_perm(X.w, X.z, sel); }
-                    CIMG_PUT2(x0[l], u) CIMG_PUT2(x1[l], u + 64) CIMG_PUT2(x2[l], u + 128) CIMG_PUT2(x3[l], u + 192)
-                    #undef CIMG_PUT2
+                    if (u < units) {
+                        const u128 x = ld128u(src + 16 * u);
+                        uint32_t* d = reinterpret_cast<uint32_t*>(lds + 8 * u);
+                        d[0] = byte_perm(x.y, x.x, sel);
+                        d[1] = byte_perm(x.w, x.z, sel);
+                    }
                 }
             }
         } else if (ts == 4) {
             const uint32_t s1 = (s & 2) ? 0x07030602u : 0x05010400u;      // bytes {0,1}/{2,3} of two elements
             const uint32_t s2 = (s & 1) ? 0x07060302u : 0x05040100u;      // then byte s of four elements
-            for (int u0 = 0; u0 < units; u0 += 256) {
-                LV<u128> x0, x1, x2, x3;
-                FOR_LANES(l) {
-                    const int u = u0 + l;
-                    if (u < units) x0[l] = ld128u(src + 16 * u);
-                    if (u + 64 < units) x1[l] = ld128u(src + 16 * (u + 64));
-                    if (u + 128 < units) x2[l] = ld128u(src + 16 * (u + 128));
-                    if (u + 192 < units) x3[l] = ld128u(src + 16 * (u + 192));
+            int u0 = 0;
+            for (; u0 + 64 * DEPTH <= units; u0 += 64 * DEPTH) {
+                LV<u128> x[DEPTH];
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { x[k][l] = ld128u(src + 16 * (u0 + 64 * k + l)); } }
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) {
+                    FOR_LANES(l) {
+                        const uint32_t t = byte_perm(x[k][l].y, x[k][l].x, s1), q = byte_perm(x[k][l].w, x[k][l].z, s1);
+                        *reinterpret_cast<uint32_t*>(lds + 4 * (u0 + 64 * k + l)) = byte_perm(q, t, s2);
+                    }
                 }
+            }
+            for (; u0 < units; u0 += 64) {
                 FOR_LANES(l) {
                     const int u = u0 + l;
-                    #define CIMG_PUT4(X, U) if ((U) < units) { const uint32_t t = byte_perm(X.y, X.x, s1), q = byte_perm(X.w, X.z, s1); \
-                        *reinterpret_cast<uint32_t*>(lds + 4 * (U)) = byte_perm(q, t, s2); }
-                    CIMG_PUT4(x0[l], u) CIMG_PUT4(x1[l], u + 64) CIMG_PUT4(x2[l], u + 128) CIMG_PUT4(x3[l], u + 192)
-                    #undef CIMG_PUT4
+                    if (u < units) {
+                        const u128 x = ld128u(src + 16 * u);
+                        const uint32_t t = byte_perm(x.y, x.x, s1), q = byte_perm(x.w, x.z, s1);
+                        *reinterpret_cast<uint32_t*>(lds + 4 * u) = byte_perm(q, t, s2);
+                    }
                 }
             }
         } else {
@@ -652,6 +687,9 @@ struct EncodeStream {
         const int neblock = bsize / ns;
         const uint8_t* src = a.raw + d.raw_off + (int64_t)j * d.blocksize;
         const bool shuf = a.p.filter == FILTER_SHUFFLE && ts > 1;
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+        const unsigned long long prof_load0_ = cimg_cycles();
+#endif
         if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
         else load_block(src, bsize, ts, shuf);
 
@@ -660,7 +698,13 @@ struct EncodeStream {
         StreamRec r;
         r.kind = REC_RAW; r.value = 0; r.csize = neblock; r.need = 0;
         uint32_t value;
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+        const bool is_run_ = plane_is_run(in, neblock, value);
+        const unsigned long long prof_load1_ = cimg_cycles();
+        if (is_run_) {
+#else
         if (plane_is_run(in, neblock, value)) {
+#endif
             r.kind = REC_RUN; r.value = (int32_t)value; r.csize = 0;
         } else {
             int need = 0;
@@ -672,6 +716,9 @@ struct EncodeStream {
                 wave_copy_l2g(lds, 0, out, neblock);
             }
         }
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+        if (a.dbg && __lane_id() == 0) a.dbg[16 * (size_t)item + 14] = prof_load1_ - prof_load0_;
+#endif
         StreamRec* dst = a.recs + (int64_t)b * spb + s;
         FOR_LANES(l) { if (l == 0) *dst = r; }
 

@@ -28,6 +28,7 @@
 // ------------------------------------------------------------------------------------------------
 #define CIMG_DEV inline
 #define CIMG_HD inline
+#define CIMG_UNROLL
 #define CIMG_DEV_NOINLINE inline
 // the workgroup's LDS: in the emulator it is whatever buffer the harness passed in
 #define CIMG_LDS_BASE(passed) (passed)
@@ -100,6 +101,7 @@ template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
 // ------------------------------------------------------------------------------------------------
 #include <hip/hip_runtime.h>
 #define CIMG_DEV __device__ __forceinline__
+#define CIMG_UNROLL _Pragma("unroll")
 #define CIMG_HD __host__ __device__ __forceinline__
 #define CIMG_DEV_NOINLINE __device__ __forceinline__   /* out-of-line was measured 10 % slower (call + flat pointers) */
 // the workgroup's LDS is always reached through the ONE pointer the kernel derives from its

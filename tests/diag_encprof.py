@@ -26,7 +26,8 @@ for plane, sl in (("plane1 (high byte)", slice(0, total_blocks)), ("plane0 (low 
     cyc = s[:, :8].mean(axis=0); cnt = s[:, 8:16].mean(axis=0)
     print(" ", plane, "total cycles %.0f" % cyc.sum(), " counts: runpath %.1f windows %.1f extends %.1f" % (cnt[0], cnt[1], cnt[2]))
     print("    " + "  ".join("%s=%.0f" % (nm, c) for nm, c in zip(names, cyc)))
-    print("    window hits at probe: first(pre/0) %.1f  second %.1f  3rd-8th %.1f  later %.1f   narrow-path hits %.1f" % tuple(cnt[3:8]))
+    print("    extend blocks run %.1f  long-extend iterations %.1f  run-path zero-literal hits %.1f  narrow-path hits %.1f" % (cnt[3], cnt[4], cnt[5], cnt[7]))
+    print("    plane load + run check %.0f cyc" % cnt[6])
     if cnt[0] > 0: print("    per runpath %.0f cyc" % (cyc[2] / cnt[0]))
     if cnt[1] > 0: print("    per window  %.0f cyc (pos+vread per iteration %.0f)" % (cyc[3] / cnt[1], cyc[1] / (cnt[0] + cnt[1])))
     if cnt[2] > 0: print("    per extend  %.0f cyc, per emit %.0f cyc" % (cyc[4] / cnt[2], cyc[5] / max(cnt[0] + cnt[2] - cnt[0], 1)))
