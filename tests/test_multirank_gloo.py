@@ -35,15 +35,31 @@ def _worker(rank, world, port, out):
         n = raw.size // chunk
         mine = shard.partition(n, world, rank, items_per_group=4)
         p = O.cparams(2)
-        sizes, digests = [], []
+        sizes, blobs = [], []
         for i in mine:
             r, c = O.compress(p, raw[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
             back = O.decompress(c)[1]
             assert back.tobytes() == raw[i * chunk:(i + 1) * chunk].tobytes()
             sizes.append(r)
+            blobs.append(np.frombuffer(c[:r], dtype=np.uint8))
         full = shard.gather_sizes(dist, mine, sizes, n)
         t = shard.max_over_ranks(dist, 1.0 + rank)
-        out.put((rank, mine.tolist(), full.tolist(), t))
+        # the exchange step: every chunk ends up on rank 0, in global order, byte for byte
+        stride = chunk + 64
+        local = np.zeros(len(mine) * stride, dtype=np.uint8)
+        for k, b in enumerate(blobs):
+            local[k * stride:k * stride + b.size] = b
+        got = shard.gather_chunks(dist, world, rank, mine, local, [k * stride for k in range(len(mine))], full, n,
+                                  dst=0, items_per_group=4)
+        digest = None
+        if rank == 0:
+            assert len(got) == n and all(g is not None for g in got)
+            digest = [int(np.frombuffer(g.tobytes(), dtype=np.uint8).astype(np.uint64).sum()) * 1000003 + g.size for g in got]
+            for i in range(n):                                    # every gathered chunk decodes to its pixels
+                assert O.decompress(got[i])[1].tobytes() == raw[i * chunk:(i + 1) * chunk].tobytes()
+        else:
+            assert got is None
+        out.put((rank, mine.tolist(), full.tolist(), t, digest))
     finally:
         dist.destroy_process_group()
 
@@ -69,6 +85,10 @@ def test_two_gloo_ranks_reproduce_single_process_sizes():
     raw = np.concatenate([c.view(np.uint8).ravel() for c in chans])
     want = [O.compress(O.cparams(2), raw[i * 65536:(i + 1) * 65536], destsize=65536 + 32)[0] for i in range(12)]
     assert res[0][1] == [0, 1, 2, 3, 8, 9, 10, 11] and res[1][1] == [4, 5, 6, 7]      # channels 0,2 / channel 1
-    for rank, mine, full, t in res:
+    blobs = [O.compress(O.cparams(2), raw[i * 65536:(i + 1) * 65536], destsize=65536 + 32) for i in range(12)]
+    want_digest = [int(np.frombuffer(c[:r], dtype=np.uint8).astype(np.uint64).sum()) * 1000003 + r for r, c in blobs]
+    for rank, mine, full, t, digest in res:
         assert full == want
         assert t == 2.0                                                                 # max over ranks
+        if rank == 0:
+            assert digest == want_digest                                                # gathered chunks == single-process chunks
