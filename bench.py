@@ -80,6 +80,7 @@ def cpu_baseline(raw_channels, budget_s=12.0):
 # (profiles/tools/collect.sh makes them).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the
 # bytes of 16-B-per-lane streaming reads -- the decoder stages compressed bytes that way (x2); the encoder's strided
 # byte-plane gather is calibrated against its known read volume (every raw byte exactly once: factor 1).
+TIMING_PERIOD = 4
 PMC_FILES = ("final_pmc_per_launch.json", "mid_pmc_per_launch.json")
 FETCH_FACTOR = {"cimg_encode_streams": 1.0, "cimg_decode_blocks": 2.0}
 
@@ -167,7 +168,9 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    eng.enable_timing(True)
+    # kernel durations: HIP events on the engine's stream around every kernel of every TIMING_PERIOD-th batch call of
+    # the timed region (an event record costs ~5 us of stream time; all eight per step were 37 us of an 800 us step)
+    eng.enable_timing(0 if os.environ.get("CIMG_BENCH_NO_EVENTS") else TIMING_PERIOD)
     eng.reset_timing()
     if dist is not None:
         dist.barrier()
@@ -234,6 +237,7 @@ def main():
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": dec_traffic,
                                 "frac": round((C + N) / dec_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if dec_avg_s > 0 else None},
             "kernels": kernels,
+            "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(chans)

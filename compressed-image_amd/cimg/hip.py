@@ -245,7 +245,8 @@ class Engine:
 
     # ---- timing ----
     def enable_timing(self, on=True):
-        load().cimg_engine_enable_timing(self.handle, 1 if on else 0)
+        """on: False/0 off, True/1 every batch call, n > 1 every n-th batch call."""
+        load().cimg_engine_enable_timing(self.handle, int(on))
 
     def reset_timing(self):
         load().cimg_engine_reset_timing(self.handle)

@@ -88,6 +88,8 @@ struct cimg_engine {
     // chunk descriptors last uploaded for encode / decode: a batch with the same geometry as the previous one
     // (the steady state of an image pipeline) skips the upload
     std::vector<uint8_t> shadow_enc, shadow_dec;
+    bool spin_sync = getenv("CIMG_SYNC_SPIN") != nullptr;
+    hipEvent_t sync_ev = nullptr;
     bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
     int num_cus = 256;
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
@@ -97,7 +99,10 @@ struct cimg_engine {
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
     int max_dyn_lds[2] = {0, 0};      // largest dynamic LDS already enabled for encode / decode
-    bool timing = false;
+    bool timing = false;              // events around the kernels of the current batch call
+    int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
+    int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
+    void begin_batch(int which) { timing = timing_period > 0 && (batch_no[which]++ % timing_period) == 0; }
     std::vector<EventPair> pending[CIMG_K_COUNT];
     std::vector<EventPair> free_events;
     double total_ms[CIMG_K_COUNT] = {0, 0, 0, 0};
@@ -283,7 +288,20 @@ void cimg_engine_destroy(cimg_engine* e)
 
 const char* cimg_last_error(const cimg_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 void* cimg_engine_stream(cimg_engine* e) { return (void*)e->stream; }
-int cimg_engine_synchronize(cimg_engine* e) { return e->hip(hipStreamSynchronize(e->stream), "hipStreamSynchronize"); }
+int cimg_engine_synchronize(cimg_engine* e)
+{
+    if (!e->spin_sync) return e->hip(hipStreamSynchronize(e->stream), "hipStreamSynchronize");
+    // a batch is a few hundred microseconds of kernels: poll an event instead of sleeping on the stream
+    if (!e->sync_ev) {
+        int rc = e->hip(hipEventCreateWithFlags(&e->sync_ev, hipEventDisableTiming), "hipEventCreate");
+        if (rc) return rc;
+    }
+    int rc = e->hip(hipEventRecord(e->sync_ev, e->stream), "hipEventRecord");
+    if (rc) return rc;
+    hipError_t q;
+    while ((q = hipEventQuery(e->sync_ev)) == hipErrorNotReady) {}
+    return e->hip(q, "hipEventQuery");
+}
 
 void* cimg_device_malloc(cimg_engine* e, size_t bytes)
 {
@@ -304,7 +322,7 @@ int cimg_memcpy_d2h(cimg_engine* e, void* h, const void* d, size_t n)
     return rc ? rc : cimg_engine_synchronize(e);
 }
 
-void cimg_engine_enable_timing(cimg_engine* e, int on) { e->timing = on != 0; }
+void cimg_engine_enable_timing(cimg_engine* e, int on) { e->timing_period = on > 0 ? on : 0; e->timing = false; e->batch_no[0] = e->batch_no[1] = 0; }
 void cimg_engine_reset_timing(cimg_engine* e)
 {
     (void)hipStreamSynchronize(e->stream);
@@ -350,6 +368,7 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
     if (nchunks <= 0) return 0;
     if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
+    e->begin_batch(0);
     EncodePlan plan;
     int rc = plan_encode_batch(to_host(p), nchunks, raw_off, nbytes, comp_off, destsize, &plan);
     if (rc < 0) return e->fail(rc, "compress batch rejected by the planner (code %d): codec %d / filter pipeline / block size %d not available on the GPU path",
@@ -416,6 +435,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     if (nchunks <= 0) return 0;
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
+    e->begin_batch(1);
     DecodePlan plan;
     int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan);
     if (rc < 0) return e->fail(rc, "decompress batch rejected by the planner (code %d)", rc);

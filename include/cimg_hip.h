@@ -94,6 +94,8 @@ int   cimg_memcpy_d2h(cimg_engine* e, void* h_dst, const void* d_src, size_t byt
 
 /* ---- kernel timing (HIP events on the engine's stream) ------------------------------------------- */
 enum { CIMG_K_ENCODE = 0, CIMG_K_LAYOUT = 1, CIMG_K_EMIT = 2, CIMG_K_DECODE = 3, CIMG_K_COUNT = 4 };
+/* on = 0: off; on = n > 0: the kernels of every n-th batch call are bracketed by events (1 = every call).  Each
+ * event record costs about 5 us of stream time, so a throughput run samples (bench.py: every 4th batch). */
 void cimg_engine_enable_timing(cimg_engine* e, int on);
 void cimg_engine_reset_timing(cimg_engine* e);
 /* total milliseconds and launch count of one kernel since the last reset (syncs the stream) */
