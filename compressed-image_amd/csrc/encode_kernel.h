@@ -97,6 +97,29 @@ CIMG_DEV void emit_literals(const uint8_t* in, int from, cimg_global_u8p out, in
     }
 }
 
+// Continues a forward match count: bytes in[ip + 4 + k] == in[mp + 4 + k] for k = from, from + 1, ... up to maxc,
+// 256 bytes per LDS round trip.  Returns the total count (match code).  Loads are unguarded: the hash table
+// follows the plane in LDS, and lanes past maxc are cut by the min.
+CIMG_DEV int match_more(const uint8_t* in, int ip, int mp, int maxc, int from, int n)
+{
+    int mcode = from;
+    for (int it = 0; it <= n / 256 + 1; ++it) {                   // k reaches maxc <= n within that many steps
+        LV<int> len;
+        LV<bool> stop;
+        FOR_LANES(l) {
+            const int k = mcode + 4 * l;
+            const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
+            const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
+            len[l] = ln;
+            stop[l] = ln < 4;
+        }
+        const uint64_t sm = ballot(stop);
+        if (sm) { const int f = ctz64(sm); return mcode + 4 * f + readlane(len, f); }
+        mcode += 256;
+    }
+    return mcode;
+}
+
 CIMG_DEV int div255(int x) { return (int)(((uint64_t)(uint32_t)x * 0x80808081ull) >> 39); }
 
 // Writes the np parked sequences (lane k = k-th sequence) at out[op..) and advances op.  The limited-output
@@ -273,16 +296,34 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         before[l] = in[ip0 - 1];
                     }
                     const int old0 = (int)readlane(slot, 0);
-                    LV<uint32_t> cv;
-                    FOR_LANES(l) { cv[l] = lds_ld32u(in, old0); }
-                    const bool hit0 = readlane(cv, 0) == v0;
+                    // second round trip: the candidate's bytes against the bytes at the probe, 256 of them -- this
+                    // decides the hit AND, for a hit, already is the match extension (no literals: nothing backwards)
+                    LV<uint32_t> cw, iw;
+                    FOR_LANES(l) {
+                        cw[l] = lds_ld32u(in, old0 + 4 * l);
+                        iw[l] = lds_ld32u(in, ip0 + 4 * l);
+                    }
+                    const bool hit0 = readlane(cw, 0) == v0;
                     have_match = true;
                     CIMG_STAT(g_emu_matches);
                     if (hit0) {
                         CIMG_PROF_COUNT(5);
-                        // zero-literal match at the post-match probe; its length depends on the candidate
+                        // zero-literal match at the post-match probe
                         FOR_LANES_W(l) { tab16[h0] = (uint16_t)ip0; }
-                        ip = ip0; mp = old0; zero_lit = true;
+                        ip = ip0; mp = old0; zero_lit = true; extended = true; backrun = 0;
+                        const int maxc = matchlimit - (ip0 + 4);
+                        LV<int> len;
+                        LV<bool> stop;
+                        FOR_LANES(l) {
+                            const int k = 4 * (l - 1);                          // lane 0 holds the four matched bytes
+                            const uint32_t x = cw[l] ^ iw[l];
+                            const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
+                            len[l] = ln;
+                            stop[l] = (l >= 1) & (ln < 4);
+                        }
+                        const uint64_t sm = ballot(stop);
+                        if (sm) { const int f = ctz64(sm); mcode = 4 * (f - 1) + readlane(len, f); }
+                        else mcode = match_more(in, ip0, old0, maxc, 252, n);
                     } else {
                         FOR_LANES_W(l) { tab16[h0] = (uint16_t)(ip0 + 1); }
                         ip = ip0 + 1; mp = ip0; zero_lit = false; extended = true;
@@ -331,7 +372,15 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     old4[l] = tab16[h[l]];
                     dup[l] = ((l >= 1) & (h[l] == h1[l])) | ((l >= 2) & (h[l] == h2[l])) | ((l >= 3) & (h[l] == h3[l]));
                 }
-                FOR_LANES(l) { hit4[l] = (l < 4) & (lds_ld32u(in, (int)old4[l]) == v[l]); }
+                // candidates of the four probes, and in the same round trip the 256 bytes that extend a match of the
+                // post-match probe (lane 0, by far the most frequent hit: it has no literals, so nothing backwards)
+                const int c0 = (int)readlane(old4, 0), p0 = sstart - 1;
+                LV<uint32_t> cw, iw;
+                FOR_LANES(l) {
+                    hit4[l] = (l < 4) & (lds_ld32u(in, (int)old4[l]) == v[l]);
+                    cw[l] = lds_ld32u(in, c0 + 4 + 4 * l);
+                    iw[l] = lds_ld32u(in, p0 + 4 + 4 * l);
+                }
                 const uint64_t hm = ballot(hit4);
                 if (hm) {
                     const int m4 = ctz64(hm);
@@ -343,6 +392,21 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         have_match = true;
                         CIMG_STAT(g_emu_matches);
                         CIMG_PROF_COUNT(7);
+                        if (m4 == 0) {
+                            extended = true; backrun = 0;
+                            const int maxc = matchlimit - (p0 + 4);
+                            LV<int> len;
+                            LV<bool> stop;
+                            FOR_LANES(l) {
+                                const uint32_t x = cw[l] ^ iw[l];
+                                const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - 4 * l, 0));
+                                len[l] = ln;
+                                stop[l] = ln < 4;
+                            }
+                            const uint64_t sm = ballot(stop);
+                            if (sm) { const int f = ctz64(sm); mcode = 4 * f + readlane(len, f); }
+                            else mcode = match_more(in, p0, c0, maxc, 256, n);
+                        }
                     }
                 }
                 CIMG_PROF_LAP(7);
@@ -439,20 +503,8 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     const int f = ctz64(sm);
                     mcode = 4 * f + readlane(len, f);
                 } else {
-                    mcode = 256;
-                    for (;;) {                                    // long match: keep counting, 256 bytes a step
-                        CIMG_PROF_COUNT(4);
-                        FOR_LANES(l) {
-                            const int k = mcode + 4 * l;
-                            const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
-                            const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
-                            len[l] = ln;
-                            stop[l] = ln < 4;
-                        }
-                        const uint64_t sm2 = ballot(stop);
-                        if (sm2) { const int f = ctz64(sm2); mcode += 4 * f + readlane(len, f); break; }
-                        mcode += 256;
-                    }
+                    CIMG_PROF_COUNT(4);
+                    mcode = match_more(in, ip, mp, maxc, 256, n);         // long match: keep counting, 256 bytes a step
                 }
                 if (backrun == 64) {                              // rare: more than 64 bytes backwards
                     int left = room - 64;
