@@ -140,6 +140,7 @@ class DeviceBuffer:
         self.ptr = load().cimg_device_malloc(engine.handle, self.nbytes)
         if not self.ptr:
             raise CodecError(-4, engine.last_error())
+        engine._buffers.add(self)
 
     def upload(self, host, offset=0):
         h = np.ascontiguousarray(host).view(np.uint8).ravel()
@@ -152,9 +153,10 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        # an engine that is closed first frees its buffers itself (Engine.close), so the handle is live here
+        if self.ptr and self.engine.handle:
             load().cimg_device_free(self.engine.handle, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -167,6 +169,8 @@ class Engine:
     """One MI355X codec engine (stream + scratch) -- wraps cimg_engine_*."""
 
     def __init__(self, device=-1):
+        import weakref
+        self._buffers = weakref.WeakSet()
         self.handle = C.c_void_p()
         rc = load().cimg_engine_create(device, C.byref(self.handle))
         if rc != 0:
@@ -174,6 +178,8 @@ class Engine:
 
     def close(self):
         if self.handle:
+            for b in list(self._buffers):          # device memory goes before the engine, whatever the GC order
+                b.free()
             load().cimg_engine_destroy(self.handle)
             self.handle = None
 

@@ -310,7 +310,12 @@ void* cimg_device_malloc(cimg_engine* e, size_t bytes)
     if (e->hip(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return nullptr;
     return p;
 }
-void cimg_device_free(cimg_engine* e, void* p) { if (p) { (void)hipSetDevice(e->device); (void)hipFree(p); } }
+void cimg_device_free(cimg_engine* e, void* p)
+{
+    if (!p) return;
+    if (e) (void)hipSetDevice(e->device);
+    (void)hipFree(p);
+}
 int cimg_memcpy_h2d(cimg_engine* e, void* d, const void* h, size_t n)
 {
     int rc = e->hip(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, e->stream), "hipMemcpyAsync(H2D)");

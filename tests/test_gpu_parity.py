@@ -185,3 +185,96 @@ def test_full_size_config2_device_resident(eng):
     assert (cbytes2 == cbytes).all() and d_comp.download().tobytes() == comp.tobytes()
     for b in (d_raw, d_out, d_comp):
         b.free()
+
+
+def test_descriptor_cache_follows_the_geometry(eng):
+    """Batches alternate between two geometries and between fresh data in the same geometry: the engine's cached
+    chunk descriptors must never be used for a batch they do not describe."""
+    a = synth.natural_channel(np.uint16, 512, 256)                 # 256 KiB
+    b = synth.tiled_channel(np.uint16, 512, 256, c=2)
+    for arr, chunk in ((a, 65536), (a, 32768), (b, 65536), (a, 65536), (b, 32768), (b, 32768)):
+        _roundtrip(eng, np.uint16, arr, chunk)
+    # same sizes, different device offsets
+    raw = a.view(np.uint8).ravel()
+    n, chunk = raw.size, 65536
+    d_raw, d_comp, d_out = eng.alloc(2 * n), eng.alloc(2 * (n + 4096)), eng.alloc(2 * n)
+    d_raw.upload(raw)
+    d_raw.upload(b.view(np.uint8).ravel(), offset=n)
+    po = O.cparams(2)
+    for base, src in ((0, raw), (n, b.view(np.uint8).ravel()), (0, raw)):
+        raw_off = base + np.arange(n // chunk) * chunk
+        comp_off = (base // chunk) * (chunk + 64) + np.arange(n // chunk) * (chunk + 64)
+        cb = eng.compress_device(hip.cparams(2), d_raw.ptr, raw_off, [chunk] * len(raw_off), d_comp.ptr, comp_off, [chunk + 32] * len(raw_off))
+        comp = d_comp.download()
+        for i in range(len(raw_off)):
+            r, want = O.compress(po, src[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+            assert cb[i] == r and comp[comp_off[i]:comp_off[i] + r].tobytes() == want
+        eng.decompress_device(d_comp.ptr, comp_off, [chunk] * len(raw_off), [32768] * len(raw_off), d_out.ptr, raw_off)
+        assert d_out.download(n, offset=base).tobytes() == src.tobytes()
+    for buf in (d_raw, d_comp, d_out):
+        buf.free()
+
+
+def test_config1_geometry_remainder_chunk_in_a_nominal_buffer(eng):
+    """BASELINE configs[0] geometry with the GPU codec (lz4): one 1024^2 uint8 channel is a single 1 MiB remainder
+    chunk compressed into the nominal 4 MiB + 32 buffer (schunk.h:73), so incompressible data stays block-framed
+    and cbytes > nbytes (SURVEY.md N7 ii)."""
+    rng = np.random.default_rng(11)
+    for arr in (synth.tiled_channel(np.uint8, 1024, 1024), rng.integers(0, 256, 1024 * 1024, dtype=np.uint8)):
+        (c,) = _roundtrip(eng, np.uint8, arr, 1024 * 1024, destsize=4 * 1024 * 1024 + 32)
+        assert struct.unpack_from("<i", c, 4)[0] == 1024 * 1024
+    assert len(c) > 1024 * 1024 + 32 and not (c[2] & 0x02)        # random bytes: framed, not memcpyed
+
+
+def test_config3_geometry_random_access_get_set_chunk(eng):
+    """BASELINE configs[2] access pattern (with the GPU codec, lz4 + byte shuffle): 8192^2 uint16 channels as 32
+    chunks of 4 MiB, chunks visited in a seeded random permutation: decode one, add 1, encode it back."""
+    rng = np.random.default_rng(99)
+    chan = synth.tiled_channel(np.uint16, 8192, 8192, c=1)
+    host = chan.view(np.uint8).ravel()
+    n, chunk = host.size, 4 * 1024 * 1024
+    nchunks, stride = n // chunk, chunk + 64
+    d_raw, d_comp, d_one = eng.alloc(n), eng.alloc(nchunks * stride), eng.alloc(chunk)
+    d_raw.upload(host)
+    raw_off, comp_off = np.arange(nchunks) * chunk, np.arange(nchunks) * stride
+    p = hip.cparams(2)
+    cbytes = eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+    po = O.cparams(2)
+    order = rng.permutation(nchunks)
+    for i in order:
+        eng.decompress_device(d_comp.ptr + int(comp_off[i]), [0], [chunk], [32768], d_one.ptr, [0])       # get_chunk
+        px = d_one.download().view(np.uint16) + np.uint16(1)
+        d_one.upload(px)
+        cbytes[i] = eng.compress_device(p, d_one.ptr, [0], [chunk], d_comp.ptr + int(comp_off[i]), [0], [chunk + 32])[0]   # set_chunk
+    comp = d_comp.download()
+    want_px = chan.ravel() + np.uint16(1)
+    for i in order[:6]:                                            # bytes against the oracle on a sample ...
+        r, want = O.compress(po, want_px.view(np.uint8)[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+        assert cbytes[i] == r and comp[comp_off[i]:comp_off[i] + r].tobytes() == want
+    eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_raw.ptr, raw_off)
+    assert d_raw.download().tobytes() == want_px.tobytes()         # ... pixels everywhere
+    for buf in (d_raw, d_comp, d_one):
+        buf.free()
+
+
+def test_config4_one_rank_share_many_images(eng):
+    """BASELINE configs[3], the share of one of 8 ranks: 8 images x 4 channels x 4096^2 float16 = 256 chunks (1 GiB)
+    in ONE batch call.  Round trip everywhere, bytes against the oracle on a sample, sizes as a checksum."""
+    imgs, chunk = 8, 4 * 1024 * 1024
+    host = np.concatenate([synth.tiled_channel(np.float16, 4096, 4096, c=c, seed=1234 + 4 * img).view(np.uint8).ravel()
+                           for img in range(imgs) for c in range(4)])
+    n = host.size
+    nchunks, stride = n // chunk, chunk + 64
+    d_raw, d_out, d_comp = eng.alloc(n), eng.alloc(n), eng.alloc(nchunks * stride)
+    d_raw.upload(host)
+    raw_off, comp_off = np.arange(nchunks) * chunk, np.arange(nchunks) * stride
+    cbytes = eng.compress_device(hip.cparams(2), d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+    assert (cbytes > 32).all() and (cbytes < chunk).all()
+    po = O.cparams(2)
+    for i in np.random.default_rng(5).choice(nchunks, 6, replace=False):
+        r, want = O.compress(po, host[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+        assert cbytes[i] == r and d_comp.download(r, offset=int(comp_off[i])).tobytes() == want, i
+    eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_out.ptr, raw_off)
+    assert d_out.download().tobytes() == host.tobytes()
+    for buf in (d_raw, d_out, d_comp):
+        buf.free()
