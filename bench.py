@@ -81,6 +81,7 @@ def cpu_baseline(raw_channels, budget_s=12.0):
 # bytes of 16-B-per-lane streaming reads -- the decoder stages compressed bytes that way (x2); the encoder's strided
 # byte-plane gather is calibrated against its known read volume (every raw byte exactly once: factor 1).
 TIMING_PERIOD = 4
+FILTER_TEXT = {"shuffle": "byte shuffle", "bitshuffle": "bitshuffle (one unsplit stream per block)", "none": "no filter"}
 PMC_FILES = ("final_pmc_per_launch.json", "mid_pmc_per_launch.json")
 FETCH_FACTOR = {"cimg_encode_streams": 1.0, "cimg_decode_blocks": 2.0}
 
@@ -109,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--family", default="tiled", choices=["tiled", "natural", "random", "zero"])
+    ap.add_argument("--filter", default="shuffle", choices=["shuffle", "bitshuffle", "none"],
+                    help="not part of the headline: the reference only uses byte shuffle")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +157,8 @@ def main():
     torch.cuda.synchronize()
 
     eng = hip.Engine(local_rank)
-    p = hip.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4)
+    filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[args.filter]
+    p = hip.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4, filters=(0, 0, 0, 0, 0, filt))
 
     def step():
         cb = eng.compress_device(p, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
@@ -211,8 +215,8 @@ def main():
         dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = algo[dom] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         dec_avg_s = ktimes[hip.K_DECODE][0] / max(ktimes[hip.K_DECODE][1], 1) * 1e-3
-        traffic, traffic_src = pmc_traffic(hip.KERNELS[dom]) if args.family == "tiled" else (None, None)
-        dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE]) if args.family == "tiled" else (None, None)
+        traffic, traffic_src = pmc_traffic(hip.KERNELS[dom]) if (args.family == "tiled" and args.filter == "shuffle") else (None, None)
+        dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE]) if (args.family == "tiled" and args.filter == "shuffle") else (None, None)
         out = {
             "metric": "compress+decompress GB/s (uncompressed side)",
             "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3),
@@ -221,7 +225,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{CHANNELS}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + byte shuffle, "
+            "config": {"workload": f"{CHANNELS}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + {FILTER_TEXT[args.filter]}, "
                                    f"32 KiB blocks, 4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks, {2 * N // BLOCK} streams), "
                                    f"device-resident, family={args.family}",
                        "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(C),
@@ -239,7 +243,7 @@ def main():
             "kernels": kernels,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle":
             out["cpu_baseline"] = cpu_baseline(chans)
         print(json.dumps(out))
     eng.close()

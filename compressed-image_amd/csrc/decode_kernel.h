@@ -627,7 +627,8 @@ struct DecodeBlock {
         // filter pipeline: exactly one of {none, shuffle, bitshuffle}, in the last slot
         filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0) { fail(ERR_CODEC_SUPPORT); return; }
-        if (filter != FILTER_NONE && filter != FILTER_SHUFFLE) { fail(ERR_CODEC_SUPPORT); return; }
+        if (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE) { fail(ERR_CODEC_SUPPORT); return; }
+        if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) { fail(ERR_CODEC_SUPPORT); return; }   // bit rows are never split
         const bool leftover_blk = bsize != blocksize;
         ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
         neblock = bsize / ns;
@@ -715,6 +716,60 @@ struct DecodeBlock {
                     }
                 }
             }
+        } else if (filter == FILTER_BITSHUFFLE) {
+            // inverse of load_block_bitshuffle: a thread gathers the 8 * ts row bytes of one group of 8 elements,
+            // transposes them back and writes 8 * ts contiguous pixels bytes
+            const int ne = bsize / ts, ne8 = ne & ~7, rowbytes = ne8 >> 3;
+            for (int g0 = tid0; g0 < rowbytes; g0 += 256) {
+                FOR_LANES(l) {
+                    const int g = g0 + l;
+                    if (g < rowbytes) {
+                        uint8_t* o = out + (int64_t)8 * g * ts;
+                        if (ts == 2 || ts == 4) {
+                            uint64_t y[4];
+                            for (int j = 0; j < ts; j++) {
+                                uint64_t x = 0;
+                                for (int k = 0; k < 8; k++) x |= (uint64_t)lds[(8 * j + k) * rowbytes + g] << (8 * k);
+                                y[j] = bit_transpose8(x);
+                            }
+                            if (ts == 2) {
+                                const uint32_t a0 = (uint32_t)y[0], a1 = (uint32_t)(y[0] >> 32), b0 = (uint32_t)y[1], b1 = (uint32_t)(y[1] >> 32);
+                                u128 q;
+                                q.x = byte_perm(b0, a0, 0x05010400u);
+                                q.y = byte_perm(b0, a0, 0x07030602u);
+                                q.z = byte_perm(b1, a1, 0x05010400u);
+                                q.w = byte_perm(b1, a1, 0x07030602u);
+                                st128u(o, q);
+                            } else {
+                                for (int half = 0; half < 2; half++) {
+                                    const uint32_t A = (uint32_t)(y[0] >> (32 * half)), B = (uint32_t)(y[1] >> (32 * half));
+                                    const uint32_t Cc = (uint32_t)(y[2] >> (32 * half)), D = (uint32_t)(y[3] >> (32 * half));
+                                    const uint32_t t0 = byte_perm(B, A, 0x05010400u), t1 = byte_perm(B, A, 0x07030602u);
+                                    const uint32_t v0 = byte_perm(D, Cc, 0x05010400u), v1 = byte_perm(D, Cc, 0x07030602u);
+                                    u128 q;
+                                    q.x = byte_perm(v0, t0, 0x05040100u);
+                                    q.y = byte_perm(v0, t0, 0x07060302u);
+                                    q.z = byte_perm(v1, t1, 0x05040100u);
+                                    q.w = byte_perm(v1, t1, 0x07060302u);
+                                    st128u(o + 16 * half, q);
+                                }
+                            }
+                        } else {
+                            for (int j = 0; j < ts; j++) {
+                                uint64_t x = 0;
+                                for (int k = 0; k < 8; k++) x |= (uint64_t)lds[(8 * j + k) * rowbytes + g] << (8 * k);
+                                const uint64_t y = bit_transpose8(x);
+                                for (int i = 0; i < 8; i++) o[i * ts + j] = (uint8_t)(y >> (8 * i));
+                            }
+                        }
+                    }
+                }
+            }
+            const int done = ne8 * ts;
+            for (int k0 = done + tid0; k0 < bsize; k0 += 256) {
+                FOR_LANES(l) { if (k0 + l < bsize) out[k0 + l] = lds[k0 + l]; }
+            }
+            return;
         } else if (filter == FILTER_NONE || ts == 1) {
             // planes are consecutive slices of the block
             for (int u0 = tid0; u0 < units; u0 += 256) {

@@ -684,6 +684,52 @@ struct EncodeStream {
         }
     }
 
+    // bitshuffle filter: the first ne8 = ne - ne % 8 elements become 8 * ts bit rows of
+    // ne8 / 8 bytes -- row 8 j + k holds bit k of byte j of every element, element i at bit i % 8 of byte i / 8 --
+    // and the remaining bytes are copied.  A lane takes one group of 8 elements: 8 * ts contiguous source bytes,
+    // one 8 x 8 bit transpose per byte position, 8 * ts single-byte LDS stores.
+    CIMG_DEV void load_block_bitshuffle(const uint8_t* src, int bsize, int ts)
+    {
+        const int ne = bsize / ts, ne8 = ne & ~7, rowbytes = ne8 >> 3;
+        for (int g0 = 0; g0 < rowbytes; g0 += 64) {
+            FOR_LANES(l) {
+                const int g = g0 + l;
+                if (g < rowbytes) {
+                    const uint8_t* e = src + (int64_t)8 * g * ts;
+                    if (ts == 2) {
+                        const u128 x = ld128u(e);
+                        for (int j = 0; j < 2; j++) {
+                            const uint32_t sel = j ? 0x07050301u : 0x06040200u;
+                            const uint64_t y = bit_transpose8((uint64_t)byte_perm(x.y, x.x, sel) | ((uint64_t)byte_perm(x.w, x.z, sel) << 32));
+                            for (int k = 0; k < 8; k++) lds[(8 * j + k) * rowbytes + g] = (uint8_t)(y >> (8 * k));
+                        }
+                    } else if (ts == 4) {
+                        const u128 x = ld128u(e), z = ld128u(e + 16);
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t s1 = (j & 2) ? 0x07030602u : 0x05010400u;
+                            const uint32_t s2 = (j & 1) ? 0x07060302u : 0x05040100u;
+                            const uint32_t lo = byte_perm(byte_perm(x.w, x.z, s1), byte_perm(x.y, x.x, s1), s2);
+                            const uint32_t hi = byte_perm(byte_perm(z.w, z.z, s1), byte_perm(z.y, z.x, s1), s2);
+                            const uint64_t y = bit_transpose8((uint64_t)lo | ((uint64_t)hi << 32));
+                            for (int k = 0; k < 8; k++) lds[(8 * j + k) * rowbytes + g] = (uint8_t)(y >> (8 * k));
+                        }
+                    } else {
+                        for (int j = 0; j < ts; j++) {
+                            uint64_t x = 0;
+                            for (int i = 0; i < 8; i++) x |= (uint64_t)e[i * ts + j] << (8 * i);
+                            const uint64_t y = bit_transpose8(x);
+                            for (int k = 0; k < 8; k++) lds[(8 * j + k) * rowbytes + g] = (uint8_t)(y >> (8 * k));
+                        }
+                    }
+                }
+            }
+        }
+        const int done = ne8 * ts;
+        for (int k0 = done; k0 < bsize; k0 += 64) {
+            FOR_LANES(l) { if (k0 + l < bsize) lds[k0 + l] = src[k0 + l]; }
+        }
+    }
+
     // phase A for an unsplit block: the whole filtered block is the stream
     CIMG_DEV void load_block(const uint8_t* src, int bsize, int ts, bool shuf)
     {
@@ -743,6 +789,7 @@ struct EncodeStream {
         const unsigned long long prof_load0_ = cimg_cycles();
 #endif
         if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
+        else if (a.p.filter == FILTER_BITSHUFFLE) load_block_bitshuffle(src, bsize, ts);
         else load_block(src, bsize, ts, shuf);
 
         const uint8_t* in = lds;

@@ -122,7 +122,6 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
     int rc = single_filter(p, &filter);
     if (rc < 0) return rc;
     if (p.compcode != CODEC_LZ4) return ERR_CODEC_SUPPORT;     // blosclz/lz4hc/zstd: not built yet
-    if (filter == FILTER_BITSHUFFLE) return ERR_CODEC_SUPPORT;  // config-3 extension: not built yet
     CodecParams& cp = plan->cp;
     cp.typesize = p.typesize > 255 ? 1 : p.typesize;
     cp.clevel = p.clevel;
@@ -142,6 +141,7 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
         d.blk0 = blk;
         blk += d.nblocks;
         if (d.blocksize > cp.max_blocksize) cp.max_blocksize = d.blocksize;
+        if (d.split && filter == FILTER_BITSHUFFLE) return ERR_CODEC_SUPPORT;   // bit rows are one stream (forced split: not built)
         if (d.split) cp.streams_per_block = cp.typesize;
         if (!d.memcpyed) {
             const int nfull = d.leftover ? d.nblocks - 1 : d.nblocks;

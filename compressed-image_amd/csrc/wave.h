@@ -250,6 +250,17 @@ CIMG_DEV void st128u(uint8_t* p, const u128& v) { memcpy(p, &v, 16); }          
 CIMG_DEV u128 ld128a(const uint8_t* p) { return *reinterpret_cast<const u128*>(__builtin_assume_aligned(p, 16)); }
 CIMG_DEV void st128a(uint8_t* p, const u128& v) { *reinterpret_cast<u128*>(__builtin_assume_aligned(p, 16)) = v; }
 
+// transpose of an 8 x 8 bit matrix held as 8 bytes (byte i = row i, least significant byte first): bit k of byte i
+// moves to bit i of byte k.  An involution; the three masked-swap rounds of the bitshuffle filter.
+CIMG_DEV uint64_t bit_transpose8(uint64_t x)
+{
+    uint64_t t;
+    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x ^= t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+    return x;
+}
+
 // unaligned 32-bit read from LDS built from two aligned dword reads (always legal on the LDS path)
 CIMG_DEV uint32_t lds_ld32u(const uint8_t* lds, int off)
 {

@@ -71,18 +71,18 @@ def test_wave_lz4_decoder_rejects_damage():
     assert E.lz4_decode(comp, 4001)[0] < 0
 
 
-def _check_batch(dtype, arr, chunk, blocksize=32768, destsize=None, order=0):
+def _check_batch(dtype, arr, chunk, blocksize=32768, destsize=None, order=0, filters=(0, 0, 0, 0, 0, 1)):
     it = np.dtype(dtype).itemsize
     raw = arr.view(np.uint8).ravel()
     sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
     dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
     E.set_write_order(order)
     try:
-        rc, cb, chunks = E.compress_batch(E.cparams(it, blocksize=blocksize), raw, sizes, dsz)
+        rc, cb, chunks = E.compress_batch(E.cparams(it, blocksize=blocksize, filters=filters), raw, sizes, dsz)
     finally:
         E.set_write_order(0)
     assert rc == 0
-    po = O.cparams(it, blocksize=blocksize)
+    po = O.cparams(it, blocksize=blocksize, filters=filters)
     off = 0
     for i, s in enumerate(sizes):
         r, c = O.compress(po, raw[off:off + s], destsize=dsz[i])
@@ -129,3 +129,18 @@ def test_reference_known_answers_through_kernels():
         _check_batch(dt, np.arange(4096).astype(dt), 256, blocksize=64)       # test_schunk.cpp:39-75
     for v in (255, 0, 199, 12):
         _check_batch(np.uint16, np.full(64 * 16, v, np.uint16), 768, blocksize=256)   # test_image.cpp chunk 768
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float16, np.uint32, np.float32, np.uint64])
+def test_bitshuffle_filter_equals_oracle(dtype):
+    """lz4 + bitshuffle (the config-3 extension): bit rows are one unsplit stream per block.  Sizes keep
+    ne % 8 == 0 in every block (the layout confirmed against c-blosc 1.21) except the
+    last case, which exercises the copied tail of the restated rule."""
+    bs = (0, 0, 0, 0, 0, 2)
+    it = np.dtype(dtype).itemsize
+    fam = synth.natural_channel if it <= 4 else (lambda d, w, h: (np.arange(w * h, dtype=np.uint64) // 7 * 0x0101).astype(np.uint64))
+    arr = fam(dtype, 1024, 96)
+    _check_batch(dtype, arr, 65536, filters=bs)                               # two 32 KiB blocks per chunk
+    _check_batch(dtype, arr, 40960, blocksize=8192, filters=bs, order=1)      # short last chunk, still multiples of 8 elements
+    _check_batch(dtype, synth.tiled_channel(dtype, 512, 40) if it <= 4 else arr, 16384, blocksize=4096, filters=bs, order=2)
+    _check_batch(dtype, arr.ravel()[:5003], 4096 * it, blocksize=1024 * it, filters=bs)   # ragged tail: ne % 8 != 0 in the leftover block

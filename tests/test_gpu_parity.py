@@ -24,13 +24,13 @@ def eng():
     e.close()
 
 
-def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9):
+def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9, filters=(0, 0, 0, 0, 0, 1)):
     it = np.dtype(dtype).itemsize
     raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
     sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
     dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
-    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize), raw, sizes, dsz)
-    po = O.cparams(it, clevel=clevel, blocksize=blocksize)
+    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters), raw, sizes, dsz)
+    po = O.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters)
     off = 0
     for i, s in enumerate(sizes):
         r, want = O.compress(po, raw[off:off + s], destsize=dsz[i])
@@ -120,7 +120,9 @@ def test_empty_batch_and_unsupported_requests_fail_loudly(eng):
         eng.compress_host(hip.cparams(2, compcode=hip.ZSTD), raw, [raw.nbytes], [raw.nbytes + 32])
     assert ei.value.code == -7
     with pytest.raises(hip.CodecError):
-        eng.compress_host(hip.cparams(2, filters=(0, 0, 0, 0, 0, hip.BITSHUFFLE)), raw, [raw.nbytes], [raw.nbytes + 32])
+        eng.compress_host(hip.cparams(2, compcode=hip.BLOSCLZ), raw, [raw.nbytes], [raw.nbytes + 32])
+    with pytest.raises(hip.CodecError):                                       # a second filter in the pipeline
+        eng.compress_host(hip.cparams(2, filters=(0, 0, 0, 0, hip.SHUFFLE, hip.BITSHUFFLE)), raw, [raw.nbytes], [raw.nbytes + 32])
 
 
 def test_corrupt_chunks_are_reported_not_crashed(eng):
@@ -272,6 +274,38 @@ def test_config4_one_rank_share_many_images(eng):
     assert (cbytes > 32).all() and (cbytes < chunk).all()
     po = O.cparams(2)
     for i in np.random.default_rng(5).choice(nchunks, 6, replace=False):
+        r, want = O.compress(po, host[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+        assert cbytes[i] == r and d_comp.download(r, offset=int(comp_off[i])).tobytes() == want, i
+    eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_out.ptr, raw_off)
+    assert d_out.download().tobytes() == host.tobytes()
+    for buf in (d_raw, d_out, d_comp):
+        buf.free()
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float16, np.uint32, np.float32, np.uint64])
+def test_bitshuffle_filter(eng, dtype):
+    """lz4 + bitshuffle (BASELINE configs[2]'s filter with the GPU codec): bytes and pixels against the oracle."""
+    bs = (0, 0, 0, 0, 0, hip.BITSHUFFLE)
+    it = np.dtype(dtype).itemsize
+    arr = synth.natural_channel(dtype, 2048, 128) if it <= 4 else (np.arange(2048 * 128, dtype=np.uint64) // 7 * 0x0101).astype(np.uint64)
+    _roundtrip(eng, dtype, arr, 262144, filters=bs)                          # 8 blocks of 32 KiB per chunk
+    _roundtrip(eng, dtype, arr, 40960, blocksize=8192, filters=bs)
+    _roundtrip(eng, dtype, arr.ravel()[:5003], 4096 * it, blocksize=1024 * it, filters=bs)   # ne % 8 != 0 in the leftover block
+
+
+def test_config3_with_bitshuffle_full_size(eng):
+    """One 8192^2 uint16 channel (32 chunks of 4 MiB), lz4 + bitshuffle, device-resident; oracle bytes on a sample."""
+    chan = synth.tiled_channel(np.uint16, 8192, 8192, c=2)
+    host = chan.view(np.uint8).ravel()
+    n, chunk = host.size, 4 * 1024 * 1024
+    nchunks, stride = n // chunk, chunk + 64
+    d_raw, d_out, d_comp = eng.alloc(n), eng.alloc(n), eng.alloc(nchunks * stride)
+    d_raw.upload(host)
+    raw_off, comp_off = np.arange(nchunks) * chunk, np.arange(nchunks) * stride
+    p = hip.cparams(2, filters=(0, 0, 0, 0, 0, hip.BITSHUFFLE))
+    cbytes = eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+    po = O.cparams(2, filters=(0, 0, 0, 0, 0, O.BITSHUFFLE))
+    for i in (0, 13, 31):
         r, want = O.compress(po, host[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
         assert cbytes[i] == r and d_comp.download(r, offset=int(comp_off[i])).tobytes() == want, i
     eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_out.ptr, raw_off)
