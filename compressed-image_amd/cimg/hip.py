@@ -23,7 +23,8 @@ EXPORTS = (
     "cimg_cparams_init", "cimg_engine_create", "cimg_engine_destroy", "cimg_last_error",
     "cimg_engine_synchronize", "cimg_engine_stream", "cimg_compress_batch_device",
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host",
-    "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h",
+    "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
+    "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
     "cimg_engine_debug_stamps", "cimg_engine_read_stamps", "cimg_shared_engine", "cimg_context_cparams",
     # include/blosc2.h
@@ -88,6 +89,9 @@ def load():
     L.cimg_device_malloc.argtypes = [vp, C.c_size_t]
     L.cimg_device_malloc.restype = vp
     L.cimg_device_free.argtypes = [vp, vp]
+    L.cimg_host_malloc.argtypes = [C.c_size_t]
+    L.cimg_host_malloc.restype = vp
+    L.cimg_host_free.argtypes = [vp]
     L.cimg_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     L.cimg_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.cimg_engine_enable_timing.argtypes = [vp, C.c_int]

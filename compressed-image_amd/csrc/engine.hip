@@ -90,6 +90,8 @@ struct cimg_engine {
     std::vector<uint8_t> shadow_enc, shadow_dec;
     bool spin_sync = getenv("CIMG_SYNC_SPIN") != nullptr;
     hipEvent_t sync_ev = nullptr;
+    std::vector<int64_t> fetch_off;     // device staging offsets / sizes of the chunks of the last host _begin
+    std::vector<int32_t> fetch_len;
     bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
     int num_cus = 256;
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
@@ -316,6 +318,13 @@ void cimg_device_free(cimg_engine* e, void* p)
     if (e) (void)hipSetDevice(e->device);
     (void)hipFree(p);
 }
+void* cimg_host_malloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void cimg_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int cimg_memcpy_h2d(cimg_engine* e, void* d, const void* h, size_t n)
 {
     int rc = e->hip(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, e->stream), "hipMemcpyAsync(H2D)");
@@ -473,12 +482,12 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
 }
 
 // ---- host-resident batches: stage through device buffers owned by the engine -----------------------
-int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
-                             const int64_t* raw_off, const int32_t* nbytes, void* h_comp, const int64_t* comp_off,
-                             const int32_t* destsize, int32_t* cbytes)
+int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
+                                   const int64_t* raw_off, const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
 {
+    e->fetch_off.clear();
     if (nchunks <= 0) return 0;
-    if (!h_raw || !h_comp || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    if (!h_raw || !raw_off || !nbytes || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
     // pack pixels back to back (16-byte aligned) and give every chunk its full destsize on the device
     std::vector<int64_t> d_raw_off((size_t)nchunks), d_comp_off((size_t)nchunks);
@@ -506,11 +515,35 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchu
     }
     rc = cimg_compress_batch_device(e, p, nchunks, e->stage_raw.p, d_raw_off.data(), nbytes, e->stage_comp.p, d_comp_off.data(), destsize, cbytes);
     if (rc) return rc;
+    e->fetch_off = std::move(d_comp_off);
+    e->fetch_len.assign(cbytes, cbytes + nchunks);
+    return 0;
+}
+
+int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp, const int64_t* comp_off)
+{
+    if (nchunks <= 0) return 0;
+    if (!h_comp || !comp_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    if ((size_t)nchunks != e->fetch_off.size()) return e->fail(ERR_INVALID_PARAM, "no compressed batch of %d chunks is waiting to be fetched", nchunks);
+    (void)hipSetDevice(e->device);
+    int rc;
     uint8_t* hc = (uint8_t*)h_comp;
     for (int i = 0; i < nchunks; i++)
-        if (cbytes[i] > 0)
-            if ((rc = e->hip(hipMemcpyAsync(hc + comp_off[i], (uint8_t*)e->stage_comp.p + d_comp_off[(size_t)i], (size_t)cbytes[i], hipMemcpyDeviceToHost, e->stream), "chunk D2H"))) return rc;
+        if (e->fetch_len[(size_t)i] > 0)
+            if ((rc = e->hip(hipMemcpyAsync(hc + comp_off[i], (uint8_t*)e->stage_comp.p + e->fetch_off[(size_t)i], (size_t)e->fetch_len[(size_t)i], hipMemcpyDeviceToHost, e->stream), "chunk D2H"))) return rc;
+    e->fetch_off.clear();
     return cimg_engine_synchronize(e);
+}
+
+int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
+                             const int64_t* raw_off, const int32_t* nbytes, void* h_comp, const int64_t* comp_off,
+                             const int32_t* destsize, int32_t* cbytes)
+{
+    if (nchunks <= 0) return 0;
+    if (!h_comp || !comp_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    const int rc = cimg_compress_batch_host_begin(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes);
+    if (rc) return rc;
+    return cimg_compress_batch_host_fetch(e, nchunks, h_comp, comp_off);
 }
 
 int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_comp, const int64_t* comp_off,
@@ -519,6 +552,7 @@ int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_co
     if (nchunks <= 0) return 0;
     if (!h_comp || !h_raw || !comp_off || !raw_off || !raw_capacity) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
+    e->fetch_off.clear();                                  // the staging area is reused: a pending _fetch is void
     const uint8_t* hc = (const uint8_t*)h_comp;
     std::vector<int64_t> d_comp_off((size_t)nchunks), d_raw_off((size_t)nchunks);
     std::vector<int32_t> nb((size_t)nchunks), bs((size_t)nchunks), cb((size_t)nchunks);

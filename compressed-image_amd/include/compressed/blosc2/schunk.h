@@ -29,11 +29,11 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			template <typename T>
 			struct lazy_chunk
 			{
-				std::variant<std::vector<std::byte>, T> value;
+				std::variant<byte_buffer, T> value;
 				size_t num_elements = 0;
 				size_t byte_size() const noexcept { return num_elements * sizeof(T); }
 				bool is_lazy() const noexcept { return std::holds_alternative<T>(value); }
-				const std::vector<std::byte>& bytes() const { return std::get<std::vector<std::byte>>(value); }
+				const byte_buffer& bytes() const { return std::get<byte_buffer>(value); }
 			};
 
 			// Lazy == false: slots always hold bytes and the element count is read from the chunk header
@@ -149,7 +149,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					if (c.is_lazy())
 						std::fill(buffer.begin(), buffer.end(), std::get<T>(c.value));
 					else
-						blosc2::decompress(ctx, buffer, std::span<const std::byte>(c.bytes()));
+						blosc2::decompress(ctx, buffer, std::span<const std::byte>(c.bytes().data(), c.bytes().size()));
 				}
 
 				// ---- replace / append -----------------------------------------------------------------------------
@@ -157,7 +157,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 				{
 					validate_chunk_index(index);
 					const size_t n = chunk_num_elements<T>(compressed);
-					m_Chunks[index].value = std::move(compressed);
+					m_Chunks[index].value = byte_buffer(std::move(compressed));
 					m_Chunks[index].num_elements = n;
 					validate_chunk_sizes();
 				}
@@ -170,7 +170,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					validate_chunk_index(index);
 					util::default_init_vector<std::byte> scratch(min_compressed_size(m_ChunkSize));
 					const size_t n = blosc2::compress<T>(compression_ctx.get(), std::span<const T>(uncompressed.data(), uncompressed.size()), std::span<std::byte>(scratch.data(), scratch.size()));
-					m_Chunks[index].value = std::vector<std::byte>(scratch.begin(), scratch.begin() + n);
+					m_Chunks[index].value = byte_buffer(std::vector<std::byte>(scratch.begin(), scratch.begin() + n));
 					m_Chunks[index].num_elements = uncompressed.size();
 					validate_chunk_sizes();
 				}
@@ -178,6 +178,12 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 				void append_chunk(std::vector<std::byte> compressed)
 				{
 					const size_t n = chunk_num_elements<T>(compressed);
+					m_Chunks.push_back(slot{ byte_buffer(std::move(compressed)), n });
+					validate_chunk_sizes();
+				}
+				void append_chunk(byte_buffer compressed)
+				{
+					const size_t n = chunk_num_elements<T>(std::span<const std::byte>(compressed.data(), compressed.size()));
 					m_Chunks.push_back(slot{ std::move(compressed), n });
 					validate_chunk_sizes();
 				}
@@ -192,7 +198,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 						throw std::runtime_error(compressed::detail::text("Error while appending chunk to super-chunk. Expected compression buffer to be at least ",
 							min_compressed_size(m_ChunkSize), " bytes but instead we got ", compression_buff.size(), " bytes"));
 					const size_t n = blosc2::compress<T>(compression_ctx.get(), std::span<const T>(uncompressed.data(), uncompressed.size()), compression_buff);
-					m_Chunks.push_back(slot{ std::vector<std::byte>(compression_buff.begin(), compression_buff.begin() + n), uncompressed.size() });
+					m_Chunks.push_back(slot{ byte_buffer(std::vector<std::byte>(compression_buff.begin(), compression_buff.begin() + n)), uncompressed.size() });
 					validate_chunk_sizes();
 				}
 				// many chunks at once (one engine call): what image::read-style producers should use

@@ -14,6 +14,7 @@
 
 #include "blosc2.h"
 #include "cimg_hip.h"
+#include "../detail/pinned_pool.h"
 
 #include "../macros.h"
 #include "../enums.h"
@@ -160,8 +161,37 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			return static_cast<size_t>(nbytes);
 		}
 		template <typename T> size_t chunk_num_elements(const std::vector<std::byte>& chunk) { return chunk_num_bytes(chunk.data()) / sizeof(T); }
+		template <typename T> size_t chunk_num_elements(std::span<const std::byte> chunk) { return chunk_num_bytes(chunk.data()) / sizeof(T); }
 
 		// ---- batches: what replaces the reference's serial chunk loops --------------------------------------------
+		/// The bytes of one compressed chunk: immutable, cheap to move, either a view into the arena a whole batch of
+		/// chunks was fetched into (shared ownership) or a vector adopted from the caller.
+		class byte_buffer
+		{
+		public:
+			byte_buffer() = default;
+			byte_buffer(std::vector<std::byte> bytes)
+			{
+				auto held = std::make_shared<std::vector<std::byte>>(std::move(bytes));
+				m_Data = held->data();
+				m_Size = held->size();
+				m_Owner = std::move(held);
+			}
+			byte_buffer(std::shared_ptr<const void> owner, const std::byte* data, size_t size) : m_Owner(std::move(owner)), m_Data(data), m_Size(size) {}
+
+			const std::byte* data() const noexcept { return m_Data; }
+			size_t size() const noexcept { return m_Size; }
+			bool empty() const noexcept { return m_Size == 0; }
+			const std::byte* begin() const noexcept { return m_Data; }
+			const std::byte* end() const noexcept { return m_Data + m_Size; }
+			const std::byte& operator[](size_t i) const noexcept { return m_Data[i]; }
+
+		private:
+			std::shared_ptr<const void> m_Owner;
+			const std::byte* m_Data = nullptr;
+			size_t m_Size = 0;
+		};
+
 		namespace batch
 		{
 			inline cimg_engine* engine()
@@ -176,15 +206,14 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 
 			// Compress many chunks in one engine call.  Every chunk gets destsize = nominal chunk size +
 			// BLOSC2_MAX_OVERHEAD, as the reference passes it (schunk.h:73, :200, :225).
-			inline std::vector<std::vector<std::byte>> compress(context_raw_ptr cctx, const std::vector<piece>& pieces, size_t nominal_chunk_bytes)
+			inline std::vector<byte_buffer> compress(context_raw_ptr cctx, const std::vector<piece>& pieces, size_t nominal_chunk_bytes)
 			{
-				std::vector<std::vector<std::byte>> out(pieces.size());
+				std::vector<byte_buffer> out(pieces.size());
 				if (pieces.empty()) return out;
 				cimg_cparams cp;
 				int rc = cimg_context_cparams(cctx, &cp);
 				if (rc < 0) throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc));
 				const size_t n = pieces.size();
-				const size_t stride = (min_compressed_size(nominal_chunk_bytes) + 63) & ~size_t{63};
 				std::vector<int64_t> raw_off(n), comp_off(n);
 				std::vector<int32_t> nbytes(n), destsize(n), cbytes(n);
 				const std::byte* base = pieces[0].data;
@@ -195,20 +224,28 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 						throw std::out_of_range(detail::text("Blosc2 chunk size may not exceed numeric limit of int32_t, got ", pieces[i].nbytes));
 					raw_off[i] = pieces[i].data - base;
 					nbytes[i] = static_cast<int32_t>(pieces[i].nbytes);
-					comp_off[i] = static_cast<int64_t>(i * stride);
 					destsize[i] = static_cast<int32_t>(min_compressed_size(nominal_chunk_bytes));
 				}
-				std::vector<std::byte> staging(n * stride);
-				rc = cimg_compress_batch_host(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(),
-					staging.data(), comp_off.data(), destsize.data(), cbytes.data());
+				// step 1: upload + compress; the chunks stay on the device and their sizes come back
+				rc = cimg_compress_batch_host_begin(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(), destsize.data(), cbytes.data());
 				if (rc < 0)
 					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
+				size_t total = 0;
 				for (size_t i = 0; i < n; ++i)
 				{
 					if (cbytes[i] <= 0)
 						throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", cbytes[i]));
-					out[i].assign(staging.begin() + comp_off[i], staging.begin() + comp_off[i] + cbytes[i]);
+					comp_off[i] = static_cast<int64_t>(total);
+					total += (static_cast<size_t>(cbytes[i]) + 63) & ~size_t{ 63 };
 				}
+				// step 2: ONE arena of exactly the compressed size (recycled, page-locked: detail/pinned_pool.h) receives
+				// every chunk by DMA; the chunks are views into it -- no staging area of nominal size, no second copy
+				std::shared_ptr<std::byte> arena = NAMESPACE_COMPRESSED_IMAGE::detail::pinned_pool::get().arena(total);
+				rc = cimg_compress_batch_host_fetch(engine(), static_cast<int32_t>(n), arena.get(), comp_off.data());
+				if (rc < 0)
+					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
+				for (size_t i = 0; i < n; ++i)
+					out[i] = byte_buffer(arena, arena.get() + comp_off[i], static_cast<size_t>(cbytes[i]));
 				return out;
 			}
 

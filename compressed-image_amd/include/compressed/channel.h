@@ -119,6 +119,16 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			require();
 			std::visit([&](auto& s) { s.set_chunk(m_CompressionContext, buffer, chunk_idx); }, *m_Schunk);
 		}
+		/// Decode into caller-owned memory (uncompressed_size() elements): no intermediate vector, no zero fill.
+		void decompress_into(std::span<T> out) const
+		{
+			require();
+			if (out.size() != uncompressed_size())
+				throw std::invalid_argument(detail::text("decompress_into: buffer holds ", out.size(), " elements, channel has ", uncompressed_size()));
+			std::vector<blosc2::batch::target> work;
+			std::visit([&](const auto& table) { table.plan_decode(out.data(), work); }, *m_Schunk);
+			blosc2::batch::decompress(work);
+		}
 		std::vector<T> get_decompressed() const
 		{
 			require();

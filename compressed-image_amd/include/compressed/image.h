@@ -148,6 +148,24 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			return out;
 		}
 
+		/// All channels into caller-owned memory (num_channels * height * width elements, channel-major): no
+		/// intermediate vectors, no zero fill -- what the Python binding uses to decode straight into a numpy array.
+		void decompress_into(std::span<T> out) const
+		{
+			size_t need = 0;
+			for (const auto& c : m_Channels) need += c.uncompressed_size();
+			if (out.size() != need)
+				throw std::invalid_argument(detail::text("decompress_into: buffer holds ", out.size(), " elements, image has ", need));
+			std::vector<blosc2::batch::target> work;
+			size_t at = 0;
+			for (const auto& c : m_Channels)
+			{
+				std::visit([&](const auto& table) { table.plan_decode(out.data() + at, work); }, c.chunks());
+				at += c.uncompressed_size();
+			}
+			blosc2::batch::decompress(work);
+		}
+
 		// ---- statistics ----------------------------------------------------------------------------------------
 		void print_statistics()
 		{

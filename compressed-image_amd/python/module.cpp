@@ -8,6 +8,7 @@
 #include <pybind11/stl.h>
 
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <string>
 #include <variant>
@@ -66,6 +67,19 @@ namespace
 		if (!c) throw py::value_error("array is not convertible to a C-contiguous buffer");
 		return { c, std::span<const T>(static_cast<const T*>(c.data()), static_cast<size_t>(c.size())) };
 	}
+	// Result arrays of get_decompressed() own a recycled page-locked buffer (compressed/detail/pinned_pool.h): the
+	// engine's D2H copy lands in it by DMA and there are no first-touch page faults.  Dropping the array returns the
+	// buffer to the pool.
+	template <typename T> py::array pooled_array(std::vector<py::ssize_t> shape)
+	{
+		size_t count = 1;
+		for (auto d : shape) count *= static_cast<size_t>(d);
+		using pool = compressed::detail::pinned_pool;
+		auto* s = new pool::block(pool::get().take(std::max<size_t>(count * sizeof(T), 1)));
+		py::capsule owner(s, [](void* p) { auto* b = static_cast<pool::block*>(p); pool::get().give(*b); delete b; });
+		return py::array(np_dtype<T>(), std::move(shape), s->p, owner);
+	}
+
 	template <typename T> py::array to_array(std::vector<T>&& pixels, std::vector<py::ssize_t> shape)
 	{
 		auto* heap = new std::vector<T>(std::move(pixels));
@@ -144,7 +158,10 @@ namespace
 		py::array get_decompressed() const
 		{
 			return visit([]<typename T>(compressed::channel<T>& ch) {
-				return to_array<T>(ch.get_decompressed(), { static_cast<py::ssize_t>(ch.height()), static_cast<py::ssize_t>(ch.width()) });
+				// numpy owns the pixels from the start (np.empty): the engine's D2H copy is the only pass over them
+				py::array out = pooled_array<T>({ static_cast<py::ssize_t>(ch.height()), static_cast<py::ssize_t>(ch.width()) });
+				ch.decompress_into(std::span<T>(static_cast<T*>(out.mutable_data()), static_cast<size_t>(out.size())));
+				return out;
 			});
 		}
 
@@ -226,11 +243,10 @@ namespace
 		py::array get_decompressed() const
 		{
 			return visit([]<typename T>(const img_ptr<T>& img) {
-				auto planes = img->get_decompressed();
-				std::vector<T> flat;
-				flat.reserve(planes.size() * img->width() * img->height());
-				for (auto& p : planes) flat.insert(flat.end(), p.begin(), p.end());
-				return to_array<T>(std::move(flat), { static_cast<py::ssize_t>(planes.size()), static_cast<py::ssize_t>(img->height()), static_cast<py::ssize_t>(img->width()) });
+				py::array out = pooled_array<T>({ static_cast<py::ssize_t>(img->num_channels()),
+					static_cast<py::ssize_t>(img->height()), static_cast<py::ssize_t>(img->width()) });
+				img->decompress_into(std::span<T>(static_cast<T*>(out.mutable_data()), static_cast<size_t>(out.size())));
+				return out;
 			});
 		}
 	};

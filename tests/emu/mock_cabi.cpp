@@ -3,6 +3,7 @@
 // (compressed-image_amd/include/compressed) and the pybind11 module can be exercised in a container
 // without a GPU.  Linked together with csrc/blosc2_shim.cpp into tests/emu/libcimg_hip_mock.so, which
 // only tests load; the product links libcimg_hip.so and has no such path.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,7 +17,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
                          uint8_t* raw, const int64_t* raw_off, int32_t* status);
 }
 
-struct cimg_engine { std::string err; };
+struct cimg_engine { std::string err; std::vector<uint8_t> stage; std::vector<int64_t> off; std::vector<int32_t> len; };
 static std::string g_err;
 
 extern "C" {
@@ -30,10 +31,13 @@ int cimg_engine_create(int, cimg_engine** out) { *out = new cimg_engine(); retur
 void cimg_engine_destroy(cimg_engine* e) { delete e; }
 const char* cimg_last_error(const cimg_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
 int cimg_engine_synchronize(cimg_engine*) { return 0; }
+void* cimg_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
+void cimg_host_free(void* p) { free(p); }
 
-int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
-                             const int32_t* nbytes, void* h_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
+int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
+                                   const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
 {
+    e->off.clear();
     if (n <= 0) return 0;
     EmuCParams ep;
     ep.typesize = p->typesize; ep.clevel = p->clevel; ep.blocksize = p->blocksize; ep.compcode = p->compcode; ep.splitmode = p->splitmode;
@@ -42,11 +46,30 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, c
     std::vector<int64_t> off((size_t)n);
     int64_t total = 0;
     for (int i = 0; i < n; i++) { off[(size_t)i] = total; total += ((int64_t)destsize[i] + 63) & ~63ll; }
-    std::vector<uint8_t> stage((size_t)total + 64);
-    const int rc = emu_compress_batch(&ep, n, (const uint8_t*)h_raw, raw_off, nbytes, stage.data(), off.data(), destsize, cbytes);
+    e->stage.resize((size_t)total + 64);
+    const int rc = emu_compress_batch(&ep, n, (const uint8_t*)h_raw, raw_off, nbytes, e->stage.data(), off.data(), destsize, cbytes);
     if (rc < 0) { e->err = "emulated compress batch rejected, code " + std::to_string(rc); return rc; }
-    for (int i = 0; i < n; i++) if (cbytes[i] > 0) memcpy((uint8_t*)h_comp + comp_off[i], stage.data() + off[(size_t)i], (size_t)cbytes[i]);
+    e->off = off;
+    e->len.assign(cbytes, cbytes + n);
     return 0;
+}
+
+int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t n, void* h_comp, const int64_t* comp_off)
+{
+    if (n <= 0) return 0;
+    if ((size_t)n != e->off.size()) { e->err = "no compressed batch is waiting to be fetched"; return -12; }
+    for (int i = 0; i < n; i++) if (e->len[(size_t)i] > 0) memcpy((uint8_t*)h_comp + comp_off[i], e->stage.data() + e->off[(size_t)i], (size_t)e->len[(size_t)i]);
+    e->off.clear();
+    return 0;
+}
+
+int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
+                             const int32_t* nbytes, void* h_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
+{
+    if (n <= 0) return 0;
+    const int rc = cimg_compress_batch_host_begin(e, p, n, h_raw, raw_off, nbytes, destsize, cbytes);
+    if (rc) return rc;
+    return cimg_compress_batch_host_fetch(e, n, h_comp, comp_off);
 }
 
 int cimg_decompress_batch_host(cimg_engine* e, int32_t n, const void* h_comp, const int64_t* comp_off, void* h_raw,
