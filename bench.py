@@ -125,12 +125,21 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (MI355X); none visible", file=sys.stderr)
         sys.exit(1)
+    # CIMG_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- rehearses the N > 1 control flow on a one-GPU box
+    # (numbers from such a run mean nothing: the ranks share one card)
+    rehearsal = os.environ.get("CIMG_BENCH_REHEARSAL") is not None
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from cimg import hip, synth
 
@@ -187,10 +196,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        csum = torch.tensor([float(cbytes.sum())], dtype=torch.float64, device="cuda")
+        csum = torch.tensor([float(cbytes.sum())], dtype=torch.float64, device=red_dev)
         dist.all_reduce(csum, op=dist.ReduceOp.SUM)
         total_c = float(csum.item())
     else:
