@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("CIMG_LIB") or os.path.join(_PKG, "libcimg_hip.so")   # CIMG_LIB: diagnostic builds
 
 K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE = 0, 1, 2, 3
-KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")
+KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")   # the decode entry times cimg_decode_lean + cimg_decode_blocks together
 BLOSCLZ, LZ4, LZ4HC, ZLIB, ZSTD = 0, 1, 2, 4, 5
 NOFILTER, SHUFFLE, BITSHUFFLE = 0, 1, 2
 MAX_OVERHEAD = 32

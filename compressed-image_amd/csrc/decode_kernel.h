@@ -34,6 +34,9 @@ struct DecodeArgs {
     int32_t lds_bytes;        // dynamic LDS size the launch provides
     uint64_t* dbg;            // diagnostics only: per-workgroup time stamps (nullptr in production)
     int32_t uniform_nblocks;  // > 0: every chunk has this many blocks (chunk = block / uniform_nblocks)
+    uint32_t* done;           // optional, per block: == gen when cimg_decode_lean already wrote the block's pixels
+    uint32_t gen;
+    uint32_t* skipped;        // optional (lean launch): counts the blocks it left to the general kernel
 };
 
 CIMG_HD int round16(int x) { return (x + 15) & ~15; }
@@ -597,13 +600,14 @@ struct DecodeBlock {
 
     CIMG_DEV void phase_a(int wave)
     {
+        mode = 3;
+        if (a.done && uni((int)a.done[b]) == (int)a.gen) return;           // the lean kernel already produced this block
         chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
         const ChunkDesc d = uniform_desc(a.descs + chunk);
         j = b - d.blk0;
         c = a.comp + d.comp_off;
         out = a.raw + d.raw_off + (int64_t)j * d.blocksize;
         bsize = (j == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
-        mode = 3;
         // the whole 32-byte header in one round trip (wave-uniform address)
         const u128 h0 = ld128u(c), h1 = ld128u(c + 16);
         const uint32_t w0 = uni(h0.x);

@@ -1,0 +1,149 @@
+// decode_lean_kernel.h -- the decode kernel for the blocks that dominate image data: byte-shuffled, split into
+// 2 or 4 byte planes, of which AT MOST ONE is LZ4-coded (the others are stored raw -- noisy low mantissa bytes --
+// or are run tokens).  Such a block needs LDS only for the one coded plane, so twice as many blocks are resident
+// per CU as in cimg_decode_blocks (which keeps the whole block in LDS), and the serial LZ4 chains -- the thing
+// decode time is made of -- run two per SIMD instead of one.  Raw planes never enter LDS: the un-shuffle merges
+// the LDS plane with 8- or 4-byte global loads of the stored planes.
+//
+// The kernel never reports an error and never guesses: any block outside its case (other filters / typesizes,
+// unsplit or leftover blocks, two coded planes, anything unusual or damaged) is left alone -- done[b] is not
+// set -- and cimg_decode_blocks, launched right behind it with the same done[] array, handles (and diagnoses) it.
+#pragma once
+#include "decode_kernel.h"
+
+namespace cimg {
+
+struct DecodeLean {
+    const DecodeArgs& a;
+    uint8_t* lds;
+    int b;
+    // results of the uniform header walk (wave-uniform, identical in all four waves)
+    int ts = 0, bsize = 0, neblock = 0, ok = 0;
+    int kind[4] = {0, 0, 0, 0};          // per plane: 0 = in LDS (decoded), 1 = stored raw at c + at[p], 2 = constant byte at[p]
+    int at[4] = {0, 0, 0, 0};
+    int lz_pos = 0, lz_cs = 0, lz_plane = -1;
+    const uint8_t* c = nullptr;
+    uint8_t* out = nullptr;
+
+    CIMG_DEV DecodeLean(const DecodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
+
+    CIMG_DEV void phase_a(int wave, int nwaves)
+    {
+        const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
+        const int j = b - d.blk0;
+        c = a.comp + d.comp_off;
+        out = a.raw + d.raw_off + (int64_t)j * d.blocksize;
+        bsize = d.blocksize;
+        if (j == d.nblocks - 1 && d.leftover) return;                          // leftover block: one unsplit stream
+        const u128 h0 = ld128u(c), h1 = ld128u(c + 16);
+        const uint32_t w0 = uni(h0.x);
+        const int flags = (int)((w0 >> 16) & 0xFF);
+        ts = (int)(w0 >> 24);
+        const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z), cbytes = (int)uni(h0.w);
+        const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
+        if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || cbytes < HEADER_LEN) return;
+        if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) return;
+        if (((b2 >> 28) & 7) != 0 || (flags & (FLAG_MEMCPYED | FLAG_DONT_SPLIT)) || (flags >> 5) != 1) return;
+        if (f0 != 0 || (f1 & 0xFF) != 0 || (int)((f1 >> 8) & 0xFF) != FILTER_SHUFFLE) return;
+        if ((ts != 2 && ts != 4) || (bsize & 15) || bsize % ts) return;
+        neblock = bsize / ts;
+        if (region_stride(neblock) + 16 > a.lds_bytes) return;
+        const int bstart = ld32s(c + HEADER_LEN + 4 * j);
+        if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) return;
+        int pos = bstart, coded = 0;
+        CIMG_UNROLL
+        for (int s = 0; s < 4; s++) {                                         // fixed trip count: kind[] / at[] stay in registers
+            if (s >= ts) continue;
+            if (cbytes - pos < 4) return;
+            const int cs = ld32s(c + pos);
+            pos += 4;
+            const int payload = cs > 0 ? cs : (cs < 0 ? 1 : 0);
+            if (payload > cbytes - pos) return;
+            if (cs == 0) { kind[s] = 2; at[s] = 0; }
+            else if (cs < 0) {
+                if (cs < -255 || !(c[pos] & 1)) return;
+                kind[s] = 2; at[s] = (-cs) & 0xFF;
+            }
+            else if (cs == neblock) { kind[s] = 1; at[s] = pos; }
+            else if (cs > neblock) return;
+            else { kind[s] = 0; lz_plane = s; lz_pos = pos; lz_cs = cs; coded++; }
+            pos += payload;
+        }
+        if (coded > 1) return;
+        ok = 1;
+        // which wave runs the serial LZ4 chain (the launch uses ONE wave per block: 9 blocks per CU and the hardware
+        // spreads them over the SIMDs; with 4 waves per block 3 of them only wait and the chains clump: 137 vs 125 us)
+        const int lzwave = (int)((((uint32_t)b * 2654435761u) >> 30) & (uint32_t)(nwaves - 1));   // nwaves is 1, 2 or 4
+        if (coded == 1 && wave == lzwave) {
+            const int rs = region_stride(neblock);
+            const int park = rs - round16(lz_cs);
+            wave_copy_g2l(c + lz_pos, lds, park, lz_cs);
+            const int rc = lz4_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes);
+            // the verdict travels to the other waves through the last LDS word of the allocation
+            FOR_LANES_W(l) { *reinterpret_cast<int32_t*>(lds + a.lds_bytes - 4) = rc; }
+        }
+    }
+
+    // 8 (ts = 2) or 4 (ts = 4) consecutive bytes of plane p, starting at plane offset `off`
+    CIMG_DEV uint32_t plane_word(int p, int off) const
+    {
+        if (kind[p] == 0) return *reinterpret_cast<const uint32_t*>(lds + off);
+        if (kind[p] == 1) return ld32u(c + at[p] + off);
+        return (uint32_t)at[p] * 0x01010101u;
+    }
+
+    CIMG_DEV void leave(int wave) const
+    {
+        if (wave == 0 && a.skipped) { FOR_LANES(l) { if (l == 0) atomic_count(a.skipped); } }
+    }
+
+    CIMG_DEV void phase_b(int wave, int nwaves)
+    {
+        if (!ok) { leave(wave); return; }
+        if (lz_plane >= 0) {
+            LV<int32_t> rc;
+            FOR_LANES(l) { rc[l] = *reinterpret_cast<const int32_t*>(lds + a.lds_bytes - 4); }
+            if (readlane(rc, 0) < 0) { leave(wave); return; }                 // damaged stream: the general kernel reports it
+        }
+        const int units = bsize >> 4;
+        const int tid0 = wave * 64, step = nwaves * 64;
+        if (ts == 2) {
+            for (int u0 = tid0; u0 < units; u0 += step) {
+                FOR_LANES(l) {
+                    const int u = u0 + l;
+                    if (u < units) {
+                        const uint32_t a0 = plane_word(0, 8 * u), a1 = plane_word(0, 8 * u + 4);
+                        const uint32_t b0 = plane_word(1, 8 * u), b1 = plane_word(1, 8 * u + 4);
+                        u128 o;
+                        o.x = byte_perm(b0, a0, 0x05010400u);
+                        o.y = byte_perm(b0, a0, 0x07030602u);
+                        o.z = byte_perm(b1, a1, 0x05010400u);
+                        o.w = byte_perm(b1, a1, 0x07030602u);
+                        st128u(out + 16 * u, o);
+                    }
+                }
+            }
+        } else {
+            for (int u0 = tid0; u0 < units; u0 += step) {
+                FOR_LANES(l) {
+                    const int u = u0 + l;
+                    if (u < units) {
+                        const uint32_t A = plane_word(0, 4 * u), B = plane_word(1, 4 * u), C = plane_word(2, 4 * u), D = plane_word(3, 4 * u);
+                        const uint32_t t0 = byte_perm(B, A, 0x05010400u), t1 = byte_perm(B, A, 0x07030602u);
+                        const uint32_t v0 = byte_perm(D, C, 0x05010400u), v1 = byte_perm(D, C, 0x07030602u);
+                        u128 o;
+                        o.x = byte_perm(v0, t0, 0x05040100u);
+                        o.y = byte_perm(v0, t0, 0x07060302u);
+                        o.z = byte_perm(v1, t1, 0x05040100u);
+                        o.w = byte_perm(v1, t1, 0x07060302u);
+                        st128u(out + 16 * u, o);
+                    }
+                }
+            }
+        }
+        if (wave == 0) { FOR_LANES_W(l) { a.done[b] = a.gen; } }
+    }
+};
+
+}  // namespace cimg

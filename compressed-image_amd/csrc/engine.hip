@@ -39,6 +39,17 @@ extern "C" __global__ __launch_bounds__(256) void cimg_emit_blocks(AssembleArgs 
     eb.run(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
 
+extern "C" __global__ __launch_bounds__(256) void cimg_decode_lean(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    DecodeLean blk(a, lds, (int)blockIdx.x);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = (int)(blockDim.x >> 6);
+    blk.phase_a(wave, nwaves);
+    __syncthreads();
+    blk.phase_b(wave, nwaves);
+}
+
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -93,6 +104,12 @@ struct cimg_engine {
     std::vector<int64_t> fetch_off;     // device staging offsets / sizes of the chunks of the last host _begin
     std::vector<int32_t> fetch_len;
     bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
+    // decode: the lean kernel (decode_lean_kernel.h) runs in front of the general one while it pays off
+    DevBuf done;                        // uint32 per block: generation stamp of the lean kernel
+    int lean_threads = 64;              // one wave per block (measured best; 64 / 128 / 256 are valid)
+    uint32_t done_gen = 0;
+    int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
+    int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
     int num_cus = 256;
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
     int enc_wgs_lds[2] = {-1, -1};
@@ -100,7 +117,7 @@ struct cimg_engine {
     bool trace = getenv("CIMG_TRACE") != nullptr;
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
-    int max_dyn_lds[2] = {0, 0};      // largest dynamic LDS already enabled for encode / decode
+    int max_dyn_lds[3] = {0, 0, 0};      // largest dynamic LDS already enabled for encode / decode
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -280,7 +297,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue, &e->done})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_out})
         if (b->p) (void)hipHostFree(b->p);
@@ -456,7 +473,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
     const size_t st_bytes = sizeof(int32_t) * (size_t)nchunks;
     if ((rc = e->upload_descs(e->descs_dec, e->shadow_dec, plan.descs.data(), desc_bytes))) return rc;
-    if ((rc = e->reserve(e->h_out, st_bytes))) return rc;
+    if ((rc = e->reserve(e->h_out, st_bytes + 32))) return rc;
     int32_t* st_dev = nullptr;                    // the status words live in pinned host memory; only failing blocks write
     if ((rc = e->device_alias(e->h_out, &st_dev))) return rc;
     memset(e->h_out.p, 0, st_bytes);
@@ -467,10 +484,55 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
         dbg = (uint64_t*)e->dbg.p;
         e->dbg_count[1] = plan.total_blocks;
     }
-    DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, dbg, plan.uniform_nblocks};
-    if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
-    if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
+    // Lean launch first (blocks with at most one LZ4-coded plane, 2x the residency), the general kernel behind it
+    // for whatever it left.  A batch the lean kernel mostly skips (e.g. every plane LZ4-coded) switches it off for
+    // the next 16 batches; the skipped count comes back through the pinned status area.
+    const bool stamping = e->stamps;
+    const bool lean = e->lean_hold == 0 && !stamping && plan.lds_lean > 0 && plan.lds_lean < plan.lds_bytes;
+    if (e->lean_hold > 0 && e->lean_hold < (1 << 30)) e->lean_hold--;
+    uint32_t* done = nullptr;
+    uint32_t* skipped_dev = nullptr;
+    volatile uint32_t* skipped_host = nullptr;
+    if (lean) {
+        const size_t done_bytes = sizeof(uint32_t) * (size_t)plan.total_blocks;
+        if (done_bytes > e->done.cap) {
+            if ((rc = e->reserve(e->done, done_bytes))) return rc;
+            if ((rc = e->hip(hipMemsetAsync(e->done.p, 0, e->done.cap, e->stream), "done memset"))) return rc;
+            e->done_gen = 0;
+        }
+        if (++e->done_gen == 0) {                  // wrapped: stale stamps could match again
+            if ((rc = e->hip(hipMemsetAsync(e->done.p, 0, e->done.cap, e->stream), "done memset"))) return rc;
+            e->done_gen = 1;
+        }
+        done = (uint32_t*)e->done.p;
+        skipped_host = (volatile uint32_t*)((uint8_t*)e->h_out.p + ((st_bytes + 15) & ~(size_t)15));
+        *skipped_host = 0;
+        skipped_dev = (uint32_t*)((uint8_t*)st_dev + ((st_bytes + 15) & ~(size_t)15));
+    }
+    EventPair ev{};
+    const bool timed = e->timing;
+    if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
+    if (lean) {
+        DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, nullptr,
+                      plan.uniform_nblocks, done, e->done_gen, skipped_dev};
+        if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))
+            rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, plan.total_blocks, e->lean_threads, plan.lds_lean);
+    }
+    if (!rc) {
+        DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, dbg,
+                      plan.uniform_nblocks, done, e->done_gen, nullptr};
+        if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
+            rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);
+    }
+    if (timed) { e->timing = true; (void)hipEventRecord(ev.b, e->stream); e->pending[CIMG_K_DECODE].push_back(ev); }
+    if (rc) return rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
+    if (lean) {
+        const uint32_t skipped = *skipped_host;
+        e->lean_batches++; e->lean_blocks_skipped += skipped; e->lean_blocks_total += plan.total_blocks;
+        if ((int64_t)skipped * 4 > plan.total_blocks) e->lean_hold = 16;
+        if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] decode: lean kernel left %u of %d blocks to the general kernel\n", skipped, plan.total_blocks);
+    }
     const int32_t* st = (const int32_t*)e->h_out.p;
     int first = 0;
     for (int i = 0; i < nchunks; i++) {

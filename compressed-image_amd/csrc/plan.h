@@ -92,6 +92,7 @@ inline int plan_chunk(const HostCParams& p, int32_t nbytes, int32_t destsize, Ch
 
 // ---- batch plans (shared by the HIP engine and the emulator) -------------------------------------
 #include "decode_kernel.h"
+#include "decode_lean_kernel.h"
 #include "encode_kernel.h"
 
 namespace cimg {
@@ -164,6 +165,7 @@ struct DecodePlan {
     std::vector<ChunkDesc> descs;
     int32_t total_blocks = 0;
     int32_t lds_bytes = 0;
+    int32_t lds_lean = 0;        // LDS of the lean launch: one plane of a 2-byte type (0: blocks too large for it)
     int32_t uniform_nblocks = 0;
 };
 
@@ -179,7 +181,7 @@ inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t
                              const int64_t* raw_off, DecodePlan* plan)
 {
     plan->descs.resize((size_t)nchunks);
-    int32_t blk = 0, lds = 0;
+    int32_t blk = 0, lds = 0, max_bs = 0;
     for (int i = 0; i < nchunks; i++) {
         ChunkDesc& d = plan->descs[(size_t)i];
         d = ChunkDesc{};
@@ -195,10 +197,12 @@ inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t
         blk += d.nblocks;
         const int need = decode_lds_bound(d.blocksize);
         if (need > lds) lds = need;
+        if (d.blocksize > max_bs) max_bs = d.blocksize;
     }
     if (lds > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
     plan->total_blocks = blk;
     plan->lds_bytes = lds;
+    plan->lds_lean = region_stride(max_bs / 2) + 16;          // decode_lean_kernel.h: the one LZ4-coded plane of a block
     plan->uniform_nblocks = uniform_blocks(plan->descs);
     return 0;
 }

@@ -85,6 +85,7 @@ template <class T> inline void lane_gather(const LV<T>& x, const LV<int>& idx, L
     for (int l = 0; l < 64; ++l) out.v[l] = tmp[l];
 }
 inline uint32_t queue_pop(uint32_t* head) { return (*head)++; }
+inline void atomic_count(uint32_t* p) { ++*p; }
 // value held by lane l-1 (lane 0 keeps its own)
 template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
 {
@@ -174,6 +175,8 @@ template <class T> CIMG_DEV void lane_gather(const LV<T>& x, const LV<int>& idx,
 }
 // one returning device-scope atomic on the queue head (MI355X_MICROARCH.md: 'dequeue', ~0.3-1.1 us)
 CIMG_DEV uint32_t queue_pop(uint32_t* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a statistics counter that may live in page-locked host memory (system scope)
+CIMG_DEV void atomic_count(uint32_t* p) { (void)__hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // Clock reads for diagnostics.  s_memtime / s_memrealtime are SMEM ops: they count on lgkmcnt together
 // with LDS reads but return OUT OF ORDER with them, so a counted wait after one no longer says which LDS
 // read is back (a plain __builtin_readcyclecounter() inside the LZ4 loops produced wrong LDS data and

@@ -72,6 +72,17 @@ def set_write_order(o):
     lib().emu_set_write_order(o)
 
 
+def set_lean(on):
+    """Run (default) or skip the lean decode kernel in front of the general one."""
+    lib().emu_set_lean(1 if on else 0)
+
+
+def lean_blocks():
+    """Blocks the lean decode kernel produced since the last call."""
+    lib().emu_lean_blocks.restype = C.c_long
+    return int(lib().emu_lean_blocks())
+
+
 def lz4_encode(src, cap=None, accel=1):
     s = _u8(src)
     n = s.size

@@ -60,6 +60,11 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     return 0;
 }
 
+int g_emu_lean = 1;            // tests switch the lean kernel off to cover the general one on every block
+long g_emu_lean_blocks = 0;    // blocks the lean kernel produced since the last emu_stats reset
+extern "C" void emu_set_lean(int on) { g_emu_lean = on; }
+extern "C" long emu_lean_blocks(void) { const long n = g_emu_lean_blocks; g_emu_lean_blocks = 0; return n; }
+
 int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_off, const int32_t* nbytes,
                          const int32_t* blocksize, uint8_t* raw, const int64_t* raw_off, int32_t* status)
 {
@@ -68,7 +73,24 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     if (rc < 0) return rc;
     memset(status, 0, sizeof(int32_t) * (size_t)nchunks);
     std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
-    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks};
+    // as the engine does: the lean kernel over every block, then the general kernel over what it left
+    std::vector<uint32_t> done((size_t)plan.total_blocks, 0);
+    const uint32_t gen = 7;
+    if (g_emu_lean) {
+        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen};
+        std::vector<uint8_t> llds((size_t)plan.lds_lean + 64);
+        for (int b = 0; b < plan.total_blocks; b++) {
+            memset(llds.data(), 0xCD, llds.size());
+            DecodeLean blk(la, llds.data(), b);
+            DecodeLean w0 = blk, w1 = blk, w2 = blk, w3 = blk;
+            DecodeLean* ws[4] = {&w0, &w1, &w2, &w3};
+            const int nw = (b & 1) ? 4 : 1;                        // both launch shapes: one wave per block, four waves per block
+            for (int w = 0; w < nw; w++) ws[w]->phase_a(w, nw);
+            for (int w = 0; w < nw; w++) ws[w]->phase_b(w, nw);
+            if (done[(size_t)b] == gen) g_emu_lean_blocks++;
+        }
+    }
+    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks, done.data(), gen};
     for (int b = 0; b < plan.total_blocks; b++) {
         memset(lds.data(), 0xCD, lds.size());
         DecodeBlock blk(da, lds.data(), b);

@@ -144,3 +144,29 @@ def test_bitshuffle_filter_equals_oracle(dtype):
     _check_batch(dtype, arr, 40960, blocksize=8192, filters=bs, order=1)      # short last chunk, still multiples of 8 elements
     _check_batch(dtype, synth.tiled_channel(dtype, 512, 40) if it <= 4 else arr, 16384, blocksize=4096, filters=bs, order=2)
     _check_batch(dtype, arr.ravel()[:5003], 4096 * it, blocksize=1024 * it, filters=bs)   # ragged tail: ne % 8 != 0 in the leftover block
+
+
+def test_lean_decode_kernel_takes_the_single_coded_plane_blocks():
+    """The lean decode kernel (one LZ4-coded plane per block, the rest stored raw or as run tokens) must produce the
+    same pixels as the general kernel, must actually take the blocks it is meant for, and must leave the others."""
+    E.lean_blocks()
+    tiled = synth.tiled_channel(np.float16, 1024, 128)               # high byte plane codes, low byte plane is stored raw
+    _check_batch(np.float16, tiled, 65536)
+    assert E.lean_blocks() == tiled.nbytes // 32768                   # every block
+    _check_batch(np.float32, synth.tiled_channel(np.float32, 512, 128), 65536)   # typesize 4: 8 KiB planes
+    f32 = E.lean_blocks()
+    zero = np.zeros((64, 1024), np.uint16)
+    zero[::7, ::5] = 3                                                # low plane codes, high plane is a run token
+    _check_batch(np.uint16, zero, 65536)
+    assert E.lean_blocks() > 0
+    _check_batch(np.uint8, synth.natural_channel(np.uint8, 512, 64), 16384)      # typesize 1: never lean
+    assert E.lean_blocks() == 0
+    _check_batch(np.uint16, synth.natural_channel(np.uint16, 1024, 64), 40000)   # ragged: leftover blocks stay general
+    E.lean_blocks()
+    E.set_lean(False)
+    try:
+        _check_batch(np.float16, tiled, 65536)                        # the general kernel alone still does everything
+        assert E.lean_blocks() == 0
+    finally:
+        E.set_lean(True)
+    assert f32 >= 0
