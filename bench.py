@@ -39,12 +39,12 @@ CHUNK = 4 * 1024 * 1024
 BLOCK = 32768
 
 
-def cpu_baseline(raw_channels, budget_s=12.0):
+def cpu_baseline(raw_channels, budget_s=10.0, threads=16):
     """Oracle compress+decompress of the same chunks on this GPU's share of the host cores (bounded sample)."""
     from concurrent.futures import ThreadPoolExecutor
     import _oracle as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(avail, 16)                                   # one GPU's share of the box
+    cores = min(avail, threads)                              # 16 = one GPU's share of an 8-GPU host's cores
     O.lib()
     p = O.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK)
     pieces = []
@@ -254,6 +254,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle":
             out["cpu_baseline"] = cpu_baseline(chans)
+            # the same port with one thread per chunk of the workload (all the chunk-level parallelism there is)
+            out["cpu_baseline_one_thread_per_chunk"] = cpu_baseline(chans, budget_s=8.0, threads=nchunks)
         print(json.dumps(out))
     eng.close()
     if dist is not None:

@@ -680,7 +680,9 @@ struct DecodeBlock {
         if (mode != 0) return;
         const int tid0 = wave * 64;
         const int units = bsize >> 4;
-        if (filter == FILTER_SHUFFLE && ts == 2 && !(bsize & 1)) {
+        // the dword fast paths need every plane to start on a dword (always true for split blocks; an unsplit
+        // shuffled block -- the leftover block of a chunk -- has planes of bsize / ts bytes)
+        if (filter == FILTER_SHUFFLE && ts == 2 && !(bsize & 1) && !(plane_base(1) & 3)) {
             const int p0 = plane_base(0), p1 = plane_base(1);
             for (int u0 = tid0; u0 < units; u0 += 256) {
                 FOR_LANES(l) {
@@ -699,7 +701,7 @@ struct DecodeBlock {
                     }
                 }
             }
-        } else if (filter == FILTER_SHUFFLE && ts == 4 && !(bsize & 3)) {
+        } else if (filter == FILTER_SHUFFLE && ts == 4 && !(bsize & 3) && !(plane_base(1) & 3)) {
             const int p0 = plane_base(0), p1 = plane_base(1), p2 = plane_base(2), p3 = plane_base(3);
             for (int u0 = tid0; u0 < units; u0 += 256) {
                 FOR_LANES(l) {

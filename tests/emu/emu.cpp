@@ -9,6 +9,12 @@
 #include <cstring>
 #include <vector>
 
+// the workgroup's LDS is a host buffer of exactly the launch size (+ slack in the normal test build; the sanitizer
+// build uses 0 so that any access past the allocation a real launch would get is reported)
+#ifndef EMU_LDS_SLACK
+#define EMU_LDS_SLACK 64
+#endif
+
 namespace cimg { int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
 
@@ -44,7 +50,7 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;
-        std::vector<uint8_t> lds((size_t)lds_bytes + 64);
+        std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK);
         uint32_t queue = 0;
         EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
@@ -53,7 +59,7 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
             es.run();
         }
     }
-    AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks};
+    AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks, nullptr, nullptr};
     for (int c = 0; c < nchunks; c++) { LayoutChunk lc(aa, c); lc.run(); }
     for (int b = 0; b < plan.total_blocks; b++) { EmitBlock eb(aa, b); for (int w = 0; w < 4; w++) eb.run(w); }
     for (int c = 0; c < nchunks; c++) cbytes[c] = layout[(size_t)c].cbytes;
@@ -72,13 +78,13 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan);
     if (rc < 0) return rc;
     memset(status, 0, sizeof(int32_t) * (size_t)nchunks);
-    std::vector<uint8_t> lds((size_t)plan.lds_bytes + 64);
+    std::vector<uint8_t> lds((size_t)plan.lds_bytes + EMU_LDS_SLACK);
     // as the engine does: the lean kernel over every block, then the general kernel over what it left
     std::vector<uint32_t> done((size_t)plan.total_blocks, 0);
     const uint32_t gen = 7;
     if (g_emu_lean) {
-        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen};
-        std::vector<uint8_t> llds((size_t)plan.lds_lean + 64);
+        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr};
+        std::vector<uint8_t> llds((size_t)plan.lds_lean + EMU_LDS_SLACK);
         for (int b = 0; b < plan.total_blocks; b++) {
             memset(llds.data(), 0xCD, llds.size());
             DecodeLean blk(la, llds.data(), b);
@@ -90,7 +96,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
             if (done[(size_t)b] == gen) g_emu_lean_blocks++;
         }
     }
-    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks, done.data(), gen};
+    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr};
     for (int b = 0; b < plan.total_blocks; b++) {
         memset(lds.data(), 0xCD, lds.size());
         DecodeBlock blk(da, lds.data(), b);
@@ -117,7 +123,7 @@ int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, 
 int emu_lz4_decode(const uint8_t* src, int csize, uint8_t* dst, int n)
 {
     const int rs = region_stride(n);
-    std::vector<uint8_t> lds((size_t)rs + 64, 0xCD);
+    std::vector<uint8_t> lds((size_t)rs + 32 + EMU_LDS_SLACK, 0xCD);
     const int park = rs - round16(csize);
     memcpy(lds.data() + park, src, (size_t)csize);
     const int rc = lz4_decode_wave(lds.data(), 0, n, park, csize, rs + 32);
