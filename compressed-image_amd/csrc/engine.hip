@@ -515,6 +515,11 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     if (lean) {
         DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, nullptr,
                       plan.uniform_nblocks, done, e->done_gen, skipped_dev};
+        if (getenv("CIMG_VERBOSE") && !e->lean_batches) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean, e->lean_threads, (size_t)plan.lds_lean);
+            fprintf(stderr, "[cimg] lean decode launch: %d bytes LDS, %d threads -> %d workgroups per CU\n", plan.lds_lean, e->lean_threads, per_cu);
+        }
         if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, plan.total_blocks, e->lean_threads, plan.lds_lean);
     }
