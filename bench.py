@@ -83,7 +83,9 @@ def cpu_baseline(raw_channels, budget_s=10.0, threads=16):
 TIMING_PERIOD = 4
 FILTER_TEXT = {"shuffle": "byte shuffle", "bitshuffle": "bitshuffle (one unsplit stream per block)", "none": "no filter"}
 PMC_FILES = ("final_pmc_per_launch.json", "mid_pmc_per_launch.json")
-FETCH_FACTOR = {"cimg_encode_streams": 1.0, "cimg_decode_blocks": 2.0}
+FETCH_FACTOR = {"cimg_encode_streams": 1.0, "cimg_decode_blocks": 2.0, "cimg_decode_lean": 2.0}
+# the decode entry of the engine timers covers two launches (lean kernel + general kernel behind it)
+PMC_KERNELS = {"cimg_decode_blocks": ("cimg_decode_lean", "cimg_decode_blocks")}
 
 
 def pmc_traffic(kernel):
@@ -94,13 +96,18 @@ def pmc_traffic(kernel):
             continue
         try:
             with open(path) as f:
-                c = json.load(f).get(kernel)
-            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return int((c["FETCH_SIZE"] * FETCH_FACTOR.get(kernel, 1.0) + c["WRITE_SIZE"]) * 1024), "profiles/r01/" + name
+                table = json.load(f)
+            total, seen = 0.0, False
+            for k in PMC_KERNELS.get(kernel, (kernel,)):
+                c = table.get(k)
+                if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    total += (c["FETCH_SIZE"] * FETCH_FACTOR.get(k, 1.0) + c["WRITE_SIZE"]) * 1024
+                    seen = True
+            if seen:
+                return int(total), "profiles/r01/" + name
         except (OSError, ValueError):
             pass
     return None, None
-
 
 
 def main():
