@@ -71,18 +71,18 @@ def test_wave_lz4_decoder_rejects_damage():
     assert E.lz4_decode(comp, 4001)[0] < 0
 
 
-def _check_batch(dtype, arr, chunk, blocksize=32768, destsize=None, order=0, filters=(0, 0, 0, 0, 0, 1)):
+def _check_batch(dtype, arr, chunk, blocksize=32768, destsize=None, order=0, filters=(0, 0, 0, 0, 0, 1), splitmode=3):
     it = np.dtype(dtype).itemsize
     raw = arr.view(np.uint8).ravel()
     sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
     dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
     E.set_write_order(order)
     try:
-        rc, cb, chunks = E.compress_batch(E.cparams(it, blocksize=blocksize, filters=filters), raw, sizes, dsz)
+        rc, cb, chunks = E.compress_batch(E.cparams(it, blocksize=blocksize, filters=filters, splitmode=splitmode), raw, sizes, dsz)
     finally:
         E.set_write_order(0)
     assert rc == 0
-    po = O.cparams(it, blocksize=blocksize, filters=filters)
+    po = O.cparams(it, blocksize=blocksize, filters=filters, splitmode=splitmode)
     off = 0
     for i, s in enumerate(sizes):
         r, c = O.compress(po, raw[off:off + s], destsize=dsz[i])
@@ -170,3 +170,15 @@ def test_lean_decode_kernel_takes_the_single_coded_plane_blocks():
     finally:
         E.set_lean(True)
     assert f32 >= 0
+
+
+def test_split_modes_follow_the_oracle():
+    """blosc2 split modes (1 always, 2 never, 3 auto, 4 forward-compatible): forced splitting of unfiltered data and
+    unsplit shuffled blocks are layouts the reference never asks for but a chunk from elsewhere may have."""
+    a = synth.natural_channel(np.uint16, 512, 80)
+    f = synth.tiled_channel(np.float32, 256, 64)
+    _check_batch(np.uint16, a, 40000, splitmode=2)                                  # never: shuffled 32 KiB blocks as one stream
+    _check_batch(np.float32, f, 32768, blocksize=8192, splitmode=2, order=1)
+    _check_batch(np.uint16, a, 40000, splitmode=1, filters=(0, 0, 0, 0, 0, 0))      # always: planes are plain slices
+    _check_batch(np.uint16, a, 40000, splitmode=4, order=2)
+    _check_batch(np.uint8, synth.natural_channel(np.uint8, 512, 64), 20000, splitmode=1)

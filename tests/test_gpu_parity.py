@@ -24,13 +24,13 @@ def eng():
     e.close()
 
 
-def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9, filters=(0, 0, 0, 0, 0, 1)):
+def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9, filters=(0, 0, 0, 0, 0, 1), splitmode=3):
     it = np.dtype(dtype).itemsize
     raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
     sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
     dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
-    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters), raw, sizes, dsz)
-    po = O.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters)
+    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters, splitmode=splitmode), raw, sizes, dsz)
+    po = O.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters, splitmode=splitmode)
     off = 0
     for i, s in enumerate(sizes):
         r, want = O.compress(po, raw[off:off + s], destsize=dsz[i])
@@ -312,3 +312,13 @@ def test_config3_with_bitshuffle_full_size(eng):
     assert d_out.download().tobytes() == host.tobytes()
     for buf in (d_raw, d_out, d_comp):
         buf.free()
+
+
+def test_split_modes(eng):
+    a = synth.natural_channel(np.uint16, 2048, 64)
+    f = synth.tiled_channel(np.float32, 1024, 64)
+    _roundtrip(eng, np.uint16, a, 131072, splitmode=2)                                # never split: shuffled blocks as one stream
+    _roundtrip(eng, np.float32, f, 65536, blocksize=8192, splitmode=2)
+    _roundtrip(eng, np.uint16, a, 40000, splitmode=1, filters=(0, 0, 0, 0, 0, 0))     # always split, no filter
+    _roundtrip(eng, np.uint16, a, 131072, splitmode=4)
+    _roundtrip(eng, np.uint8, synth.natural_channel(np.uint8, 1024, 64), 20000, splitmode=1)
