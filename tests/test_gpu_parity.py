@@ -322,3 +322,39 @@ def test_split_modes(eng):
     _roundtrip(eng, np.uint16, a, 40000, splitmode=1, filters=(0, 0, 0, 0, 0, 0))     # always split, no filter
     _roundtrip(eng, np.uint16, a, 131072, splitmode=4)
     _roundtrip(eng, np.uint8, synth.natural_channel(np.uint8, 1024, 64), 20000, splitmode=1)
+
+
+def test_general_decode_kernel_alone_still_covers_every_block():
+    """The lean decode launch takes most image blocks in the other tests; with it switched off (CIMG_NO_LEAN, read
+    when an engine is created) the general kernel must produce the same pixels for the same chunks."""
+    os.environ["CIMG_NO_LEAN"] = "1"
+    try:
+        e2 = hip.Engine(0)
+    finally:
+        del os.environ["CIMG_NO_LEAN"]
+    try:
+        for dtype, arr in ((np.float16, synth.tiled_channel(np.float16, 2048, 256)), (np.float32, synth.tiled_channel(np.float32, 1024, 128)),
+                           (np.uint16, synth.natural_channel(np.uint16, 1024, 100)), (np.uint8, synth.natural_channel(np.uint8, 1024, 64))):
+            _roundtrip(e2, dtype, arr, 262144)
+            _roundtrip(e2, dtype, arr, 40000 // np.dtype(dtype).itemsize * np.dtype(dtype).itemsize)
+    finally:
+        e2.close()
+
+
+def test_lean_and_general_decode_agree_on_mixed_batches(eng):
+    """One batch holding chunks the lean kernel takes (tiled float16), chunks it must leave (both planes coded, ragged
+    leftover blocks, typesize 1) and a damaged chunk: every good chunk decodes, the damaged one is reported."""
+    t = synth.tiled_channel(np.float16, 1024, 64).view(np.uint8).ravel()           # 128 KiB
+    nat = synth.natural_channel(np.uint16, 1024, 50).view(np.uint8).ravel()         # 100 KiB: ragged
+    u8 = synth.natural_channel(np.uint8, 1024, 64).ravel()
+    chunks = []
+    for ts, raw in ((2, t), (2, nat), (1, u8)):
+        chunks += eng.compress_host(hip.cparams(ts), raw, [raw.size], [raw.size + 32])
+    bad = bytearray(chunks[0])
+    first = struct.unpack_from("<i", chunks[0], 32)[0]
+    for k in range(first + 8, first + 60):
+        bad[k] ^= 0xA5
+    outs, status = eng.decompress_host(chunks + [bytes(bad)], check=False)
+    assert list(status[:3]) == [0, 0, 0]
+    assert outs[0].tobytes() == t.tobytes() and outs[1].tobytes() == nat.tobytes() and outs[2].tobytes() == u8.tobytes()
+    assert status[3] < 0 or outs[3].tobytes() != t.tobytes()
