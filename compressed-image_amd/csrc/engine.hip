@@ -110,6 +110,7 @@ struct cimg_engine {
     uint32_t done_gen = 0;
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
+    uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over (1: unknown yet -> general kernel enqueued up front)
     int num_cus = 256;
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
     int enc_wgs_lds[2] = {-1, -1};
@@ -523,9 +524,12 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
         if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, plan.total_blocks, e->lean_threads, plan.lds_lean);
     }
-    if (!rc) {
-        DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, dbg,
-                      plan.uniform_nblocks, done, e->done_gen, nullptr};
+    // The general kernel goes right behind the lean one -- unless the previous lean batch left it nothing to do: then
+    // it is only launched (and waited for) if the skipped count that comes back says a block is still undecoded.
+    const bool general_now = !lean || e->lean_last_skipped != 0;
+    DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, dbg,
+                  plan.uniform_nblocks, done, e->done_gen, nullptr};
+    if (!rc && general_now) {
         if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);
     }
@@ -535,8 +539,15 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     if (lean) {
         const uint32_t skipped = *skipped_host;
         e->lean_batches++; e->lean_blocks_skipped += skipped; e->lean_blocks_total += plan.total_blocks;
+        e->lean_last_skipped = skipped;
         if ((int64_t)skipped * 4 > plan.total_blocks) e->lean_hold = 16;
-        if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] decode: lean kernel left %u of %d blocks to the general kernel\n", skipped, plan.total_blocks);
+        if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] decode: lean kernel left %u of %d blocks to the general kernel%s\n", skipped, plan.total_blocks,
+                                            (!general_now && skipped) ? " (launched late)" : "");
+        if (!general_now && skipped) {
+            if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
+            if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
+            if ((rc = cimg_engine_synchronize(e))) return rc;
+        }
     }
     const int32_t* st = (const int32_t*)e->h_out.p;
     int first = 0;
