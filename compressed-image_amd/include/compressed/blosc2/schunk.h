@@ -130,6 +130,20 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					}
 				}
 
+				/// Same for the chunks [first, first + count): `pixels` receives them back to back.
+				void plan_decode_range(T* pixels, size_t first, size_t count, std::vector<batch::target>& work) const
+				{
+					size_t offset = 0;
+					for (size_t i = first; i < first + count; ++i)
+					{
+						validate_chunk_index(i);
+						const auto& c = m_Chunks[i];
+						if (c.is_lazy()) std::fill(pixels + offset, pixels + offset + c.num_elements, std::get<T>(c.value));
+						else work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels + offset), c.num_elements * sizeof(T) });
+						offset += c.num_elements;
+					}
+				}
+
 				std::vector<T> chunk(context_ptr& ctx, size_t index) const { return chunk(ctx.get(), index); }
 				std::vector<T> chunk(context_raw_ptr ctx, size_t index) const
 				{
@@ -158,6 +172,14 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					validate_chunk_index(index);
 					const size_t n = chunk_num_elements<T>(compressed);
 					m_Chunks[index].value = byte_buffer(std::move(compressed));
+					m_Chunks[index].num_elements = n;
+					validate_chunk_sizes();
+				}
+				void set_chunk(byte_buffer compressed, size_t index)
+				{
+					validate_chunk_index(index);
+					const size_t n = chunk_num_elements<T>(std::span<const std::byte>(compressed.data(), compressed.size()));
+					m_Chunks[index].value = std::move(compressed);
 					m_Chunks[index].num_elements = n;
 					validate_chunk_sizes();
 				}

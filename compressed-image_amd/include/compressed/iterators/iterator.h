@@ -2,17 +2,23 @@
 // current chunk into an internal buffer and hands out a chunk_span; moving on (or destruction)
 // recompresses it and stores it back.  Same contract as the reference (compressed/iterators/iterator.h:
 // operator* :97-141, destructor :72-93, ++ :143-156), including that a visited chunk is always written
-// back.  One decode + one encode per chunk, each a single-chunk engine call; a whole-channel modify is
-// cheaper through get_decompressed() + a fresh channel (two batched calls).
+// back.  What differs is the granularity of the engine calls: the reference decodes and re-encodes one chunk at
+// a time; here the iterator works on a WINDOW of up to 8 chunks -- one batched decode when the window is entered
+// (into a recycled page-locked buffer), one batched encode of the visited chunks when it is left or the iterator
+// dies.  A visited chunk therefore reaches the channel when its window is flushed, not at ++; code that reads a
+// chunk back through the channel while still iterating over the same window sees the old bytes.
 #pragma once
 #include <cstddef>
+#include <algorithm>
 #include <iterator>
+#include <memory>
 #include <span>
 #include <stdexcept>
 #include <variant>
 #include <vector>
 #include "../blosc2/schunk.h"
 #include "../containers/chunk_span.h"
+#include "../detail/pinned_pool.h"
 #include "../macros.h"
 
 namespace NAMESPACE_COMPRESSED_IMAGE
@@ -50,7 +56,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 				flush();
 				m_Schunk = other.m_Schunk; m_Cctx = other.m_Cctx; m_Dctx = other.m_Dctx;
 				m_Index = other.m_Index; m_Width = other.m_Width; m_Height = other.m_Height;
-				m_Live = npos;
+				m_WinFirst = npos;
 			}
 			return *this;
 		}
@@ -64,15 +70,15 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		{
 			if (!m_Schunk || !m_Cctx || !m_Dctx || m_Index >= num_chunks())
 				throw std::runtime_error("Invalid Iterator struct encountered, cannot dereference item");
-			if (m_Live != m_Index)
+			if (m_WinFirst == npos || m_Index < m_WinFirst || m_Index >= m_WinFirst + m_WinElems.size())
 			{
-				flush();                                   // recompress the chunk handed out before
-				const size_t elems = std::visit([&](auto& s) { return s.chunk_elements(m_Index); }, *m_Schunk);
-				m_Pixels.resize(elems);
-				std::visit([&](auto& s) { s.chunk(m_Dctx, std::span<T>(m_Pixels), m_Index); }, *m_Schunk);
-				m_Live = m_Index;
+				flush();                                   // recompress what the previous window handed out
+				load_window(m_Index);
 			}
-			return value_type(std::span<T>(m_Pixels), m_Width, m_Height, m_Index, chunk_bytes());
+			const size_t k = m_Index - m_WinFirst;
+			m_Visited[k] = true;
+			T* px = reinterpret_cast<T*>(m_Buffer.get()) + m_WinOffset[k];
+			return value_type(std::span<T>(px, m_WinElems[k]), m_Width, m_Height, m_Index, chunk_bytes());
 		}
 
 		channel_iterator& operator++()
@@ -104,21 +110,54 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		size_t m_Index = 0;
 		size_t m_Width = 0;
 		size_t m_Height = 0;
-		size_t m_Live = npos;                     // index of the chunk currently decompressed in m_Pixels
-		std::vector<T> m_Pixels;
+		static constexpr size_t s_window_chunks = 8;
+		size_t m_WinFirst = npos;                 // first chunk of the decoded window (npos: none)
+		std::vector<size_t> m_WinOffset, m_WinElems;   // element offset / count of each window chunk inside m_Buffer
+		std::vector<bool> m_Visited;              // handed out since the window was loaded -> written back on flush
+		std::shared_ptr<std::byte> m_Buffer;      // the window's pixels (recycled page-locked memory)
 
 		size_t num_chunks() const { return m_Schunk ? std::visit([](auto& s) { return s.num_chunks(); }, *m_Schunk) : 0; }
 
-		// write the live chunk back, compressed
+		// decode chunks [first, first + s_window_chunks) with ONE engine call
+		void load_window(size_t first)
+		{
+			const size_t count = std::min(s_window_chunks, num_chunks() - first);
+			m_WinOffset.assign(count, 0);
+			m_WinElems.assign(count, 0);
+			m_Visited.assign(count, false);
+			size_t total = 0;
+			for (size_t k = 0; k < count; ++k)
+			{
+				m_WinOffset[k] = total;
+				m_WinElems[k] = std::visit([&](auto& s) { return s.chunk_elements(first + k); }, *m_Schunk);
+				total += m_WinElems[k];
+			}
+			m_Buffer = detail::pinned_pool::get().arena(std::max<size_t>(total * sizeof(T), 1));
+			std::vector<blosc2::batch::target> work;
+			std::visit([&](auto& s) { s.plan_decode_range(reinterpret_cast<T*>(m_Buffer.get()), first, count, work); }, *m_Schunk);
+			blosc2::batch::decompress(work);
+			m_WinFirst = first;
+		}
+
+		// write the visited chunks of the window back, compressed with ONE engine call
 		void flush()
 		{
-			if (m_Live == npos || !m_Schunk) return;
-			std::vector<std::byte> scratch(blosc2::min_compressed_size(chunk_bytes()));
-			const size_t n = blosc2::compress<T>(m_Cctx, std::span<const T>(m_Pixels), std::span<std::byte>(scratch));
-			scratch.resize(n);
-			const size_t at = m_Live;
-			m_Live = npos;
-			std::visit([&](auto& s) { s.set_chunk(std::move(scratch), at); }, *m_Schunk);
+			if (m_WinFirst == npos || !m_Schunk) return;
+			std::vector<blosc2::batch::piece> pieces;
+			std::vector<size_t> where;
+			for (size_t k = 0; k < m_Visited.size(); ++k)
+				if (m_Visited[k])
+				{
+					pieces.push_back({ m_Buffer.get() + m_WinOffset[k] * sizeof(T), m_WinElems[k] * sizeof(T) });
+					where.push_back(m_WinFirst + k);
+				}
+			const size_t first = m_WinFirst;
+			m_WinFirst = npos;
+			(void)first;
+			if (pieces.empty()) return;
+			auto chunks = blosc2::batch::compress(m_Cctx, pieces, chunk_bytes());
+			for (size_t i = 0; i < chunks.size(); ++i)
+				std::visit([&](auto& s) { s.set_chunk(std::move(chunks[i]), where[i]); }, *m_Schunk);
 		}
 	};
 }

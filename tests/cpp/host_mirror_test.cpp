@@ -94,6 +94,35 @@ static void channel_cases()
 		for (auto chunk : c) for (auto& px : chunk) px = 128;
 		for (auto v : c.get_decompressed()) CHECK(v == 128);
 	}
+	// the iterator works on windows of 8 chunks: 21 chunks = two full windows and a short one; every chunk gets its
+	// index, a second pass reads them back and rewrites only the odd ones, a partial pass stops inside a window
+	{
+		const size_t w = 32, h = 84, chunk = 32 * 4 * sizeof(uint16_t);           // 4 scanlines per chunk -> 21 chunks
+		std::vector<uint16_t> d(w * h, 7);
+		channel<uint16_t> c(std::span<const uint16_t>(d), w, h, enums::codec::lz4, 9, 128, chunk);
+		CHECK(c.num_chunks() == 21);
+		for (auto it = c.begin(); it != c.end(); ++it) { auto ch = *it; for (auto& px : ch) px = static_cast<uint16_t>(it.chunk_index()); }
+		auto all = c.get_decompressed();
+		for (size_t i = 0; i < all.size(); ++i) CHECK(all[i] == i / (w * 4));
+		for (auto it = c.begin(); it != c.end(); ++it)
+		{
+			auto ch = *it;
+			for (auto& px : ch) { CHECK(px == it.chunk_index()); if (it.chunk_index() & 1) px = 1000; }
+		}
+		all = c.get_decompressed();
+		for (size_t i = 0; i < all.size(); ++i) CHECK(all[i] == (((i / (w * 4)) & 1) ? 1000 : i / (w * 4)));
+		{
+			auto it = c.begin();
+			for (int k = 0; k < 10; ++k, ++it) { auto ch = *it; for (auto& px : ch) px = 5; }     // stops in the second window
+		}                                                                                     // destructor flushes it
+		all = c.get_decompressed();
+		for (size_t i = 0; i < all.size(); ++i) CHECK(all[i] == (i / (w * 4) < 10 ? 5 : (((i / (w * 4)) & 1) ? 1000 : i / (w * 4))));
+		// lazy channel: windows mix fill-value slots and real chunks
+		auto z = channel<uint16_t>::full(w, h, 9, enums::codec::lz4, 9, 128, chunk);
+		for (auto it = z.begin(); it != z.end(); ++it) { auto ch = *it; if (it.chunk_index() == 3 || it.chunk_index() == 12) for (auto& px : ch) px = 77; }
+		all = z.get_decompressed();
+		for (size_t i = 0; i < all.size(); ++i) CHECK(all[i] == ((i / (w * 4) == 3 || i / (w * 4) == 12) ? 77 : 9));
+	}
 	// lazy factories (python test_channel.py:71-190 through the C++ surface)
 	{
 		auto z = channel<float>::zeros(123, 456, enums::codec::lz4, 9, s_default_blocksize, 123 * sizeof(float) * 10);
