@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -103,6 +104,9 @@ struct cimg_engine {
     hipEvent_t sync_ev = nullptr;
     std::vector<int64_t> fetch_off;     // device staging offsets / sizes of the chunks of the last host _begin
     std::vector<int32_t> fetch_len;
+    // one batch at a time per engine: the calls share the stream, the staging buffers and the result area.
+    // (recursive: the host-buffer calls run the device calls inside)
+    std::recursive_mutex mu;
     bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
     // decode: the lean kernel (decode_lean_kernel.h) runs in front of the general one while it pays off
     DevBuf done;                        // uint32 per block: generation stamp of the lean kernel
@@ -397,6 +401,7 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
                                const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
                                void* d_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
 {
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
@@ -464,6 +469,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
                                  const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
                                  int32_t* status)
 {
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
@@ -563,6 +569,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
 int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
                                    const int64_t* raw_off, const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
 {
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
     e->fetch_off.clear();
     if (nchunks <= 0) return 0;
     if (!h_raw || !raw_off || !nbytes || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
@@ -600,6 +607,7 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
 
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp, const int64_t* comp_off)
 {
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!h_comp || !comp_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     if ((size_t)nchunks != e->fetch_off.size()) return e->fail(ERR_INVALID_PARAM, "no compressed batch of %d chunks is waiting to be fetched", nchunks);
@@ -617,6 +625,7 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchu
                              const int64_t* raw_off, const int32_t* nbytes, void* h_comp, const int64_t* comp_off,
                              const int32_t* destsize, int32_t* cbytes)
 {
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!h_comp || !comp_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     const int rc = cimg_compress_batch_host_begin(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes);
@@ -627,6 +636,7 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchu
 int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_comp, const int64_t* comp_off,
                                void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity, int32_t* status)
 {
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!h_comp || !h_raw || !comp_off || !raw_off || !raw_capacity) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <span>
 #include <stdexcept>
 #include <string>
@@ -226,6 +227,9 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					nbytes[i] = static_cast<int32_t>(pieces[i].nbytes);
 					destsize[i] = static_cast<int32_t>(min_compressed_size(nominal_chunk_bytes));
 				}
+				// _begin and _fetch belong together: no other thread's batch may run on the shared engine in between
+				static std::mutex pair_mutex;
+				std::lock_guard<std::mutex> pair_lock(pair_mutex);
 				// step 1: upload + compress; the chunks stay on the device and their sizes come back
 				rc = cimg_compress_batch_host_begin(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(), destsize.data(), cbytes.data());
 				if (rc < 0)

@@ -10,6 +10,8 @@
 #include <functional>
 #include <numeric>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "compressed/channel.h"
@@ -204,6 +206,29 @@ static void zip_cases()
 	CHECK(a[0] == 0 && a[2] == 0 && a[3] == 4);                   // elements are references
 }
 
+// several host threads on the one shared engine: batches are serialised inside the library, results stay correct
+static void thread_cases()
+{
+	std::atomic<int> bad{ 0 };
+	auto work = [&](int seed) {
+		for (int rep = 0; rep < 4; ++rep)
+		{
+			const size_t w = 64 + 8 * static_cast<size_t>(seed), h = 48;
+			std::vector<uint16_t> d(w * h);
+			for (size_t i = 0; i < d.size(); ++i) d[i] = static_cast<uint16_t>((i / 7) * (seed + 1) + rep);
+			channel<uint16_t> c(std::span<const uint16_t>(d), w, h, enums::codec::lz4, 9, 512, w * 8 * sizeof(uint16_t));
+			if (c.get_decompressed() != d) ++bad;
+			for (auto chunk : c) for (auto& px : chunk) px = static_cast<uint16_t>(px + 3);
+			auto back = c.get_decompressed();
+			for (size_t i = 0; i < d.size(); ++i) if (back[i] != static_cast<uint16_t>(d[i] + 3)) { ++bad; break; }
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 0; t < 4; ++t) pool.emplace_back(work, t);
+	for (auto& t : pool) t.join();
+	CHECK(bad.load() == 0);
+}
+
 int main()
 {
 	schunk_cases<uint8_t>(); schunk_cases<uint16_t>(); schunk_cases<uint32_t>(); schunk_cases<float>();
@@ -211,6 +236,7 @@ int main()
 	image_cases<uint8_t>(); image_cases<uint16_t>(); image_cases<uint32_t>(); image_cases<float>();
 	chunk_span_cases();
 	zip_cases();
+	thread_cases();
 	std::printf("%d checks, %d failures\n", g_checks, g_failures);
 	return g_failures ? 1 : 0;
 }

@@ -13,7 +13,7 @@ def _build_and_run(libdir, lib, exe):
     out = os.path.join(ROOT, "tests", "cpp", exe)
     subprocess.check_call(["g++", "-std=c++20", "-O1", "-g", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                            "-I", os.path.join(ROOT, "compressed-image_amd", "include"), SRC, "-o", out,
-                           "-L", libdir, "-l" + lib, "-Wl,-rpath," + libdir])
+                           "-L", libdir, "-l" + lib, "-Wl,-rpath," + libdir, "-pthread"])
     res = subprocess.run([out], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert "0 failures" in res.stdout
