@@ -182,3 +182,22 @@ def test_split_modes_follow_the_oracle():
     _check_batch(np.uint16, a, 40000, splitmode=1, filters=(0, 0, 0, 0, 0, 0))      # always: planes are plain slices
     _check_batch(np.uint16, a, 40000, splitmode=4, order=2)
     _check_batch(np.uint8, synth.natural_channel(np.uint8, 512, 64), 20000, splitmode=1)
+
+
+def test_unusual_typesizes():
+    """Element sizes the Python surface never produces but the C ABI accepts: 3 (packed RGB), 16 (the largest that
+    still splits into byte planes), 20 (too wide to split: one shuffled stream per block)."""
+    rng = np.random.default_rng(21)
+    for ts in (3, 16, 20):
+        n = 3000
+        base = (np.arange(n)[:, None] // 9 * (np.arange(ts)[None, :] + 1)).astype(np.uint8)
+        base[:, 0] = rng.integers(0, 256, n)                               # one noisy byte plane
+        raw = np.ascontiguousarray(base).ravel()
+        sizes = [raw.size]
+        for blocksize in (4096 // ts * ts, 960):
+            rc, cb, chunks = E.compress_batch(E.cparams(ts, blocksize=blocksize), raw, sizes, [raw.size + 32])
+            assert rc == 0
+            r, c = O.compress(O.cparams(ts, blocksize=blocksize), raw, destsize=raw.size + 32)
+            assert cb[0] == r and chunks[0] == c, (ts, blocksize)
+            rc, st, outs = E.decompress_batch([chunks[0]], sizes, [O.cbuffer_sizes(c)[2]], misalign=1)
+            assert rc == 0 and not any(st) and outs[0].tobytes() == raw.tobytes()

@@ -358,3 +358,19 @@ def test_lean_and_general_decode_agree_on_mixed_batches(eng):
     assert list(status[:3]) == [0, 0, 0]
     assert outs[0].tobytes() == t.tobytes() and outs[1].tobytes() == nat.tobytes() and outs[2].tobytes() == u8.tobytes()
     assert status[3] < 0 or outs[3].tobytes() != t.tobytes()
+
+
+def test_unusual_typesizes(eng):
+    """Element sizes 3 (packed RGB), 16 (largest that still splits) and 20 (one shuffled stream per block) through the C ABI."""
+    rng = np.random.default_rng(21)
+    for ts in (3, 16, 20):
+        n = 40000
+        base = (np.arange(n)[:, None] // 9 * (np.arange(ts)[None, :] + 1)).astype(np.uint8)
+        base[:, 0] = rng.integers(0, 256, n)
+        raw = np.ascontiguousarray(base).ravel()
+        for blocksize in (32768 // ts * ts, 4096 // ts * ts):
+            (c,) = eng.compress_host(hip.cparams(ts, blocksize=blocksize), raw, [raw.size], [raw.size + 32])
+            r, want = O.compress(O.cparams(ts, blocksize=blocksize), raw, destsize=raw.size + 32)
+            assert len(c) == r and c == want, (ts, blocksize)
+            outs, st = eng.decompress_host([c])
+            assert not st.any() and outs[0].tobytes() == raw.tobytes()
