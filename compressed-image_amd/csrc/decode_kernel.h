@@ -10,13 +10,16 @@
 //              raw stream         -> 16-byte global loads -> LDS
 //              LZ4 stream         -> compressed bytes are parked at the END of the stream's LDS
 //                                    region and decoded *in place* towards the front by one wave
-//                                    (64-byte register window over the token stream, lane-parallel
-//                                    literal and match copies, overlap-safe for offset < 64)
+//                                    (every lane parses "a token starts at my byte" for the next 64
+//                                    input bytes, a scalar walk follows the real chain, literals of the
+//                                    whole batch go out in one store, matches run in order)
 //   barrier
 //   phase B  all four waves undo the byte shuffle straight out of LDS (v_perm byte transposes for
 //            typesize 2 and 4) and store the pixels with 16-byte coalesced writes.
 //
 // HBM traffic per block: compressed bytes read once, pixels written once (the algorithmic bytes).
+// Blocks with at most one LZ4-coded plane are normally taken by the lean launch in front of this kernel
+// (decode_lean_kernel.h); `done[b] == gen` marks them and this kernel skips them.
 // Memcpyed and special-zero chunks skip LDS.  Written in the wave.h vocabulary; see wave.h for the
 // host-emulation build used by tests/emu.
 #pragma once

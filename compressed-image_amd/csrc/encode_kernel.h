@@ -5,7 +5,8 @@
 // 32 KiB block): streams differ wildly in cost (a noisy low-byte plane is scanned once and stored raw,
 // a smooth high-byte plane is hundreds of matches), so the stream -- not the block -- is the
 // scheduling unit; LDS per workgroup is exactly plane + hash table = 32 KiB, five workgroups per CU.
-// Workgroups w and w+8 take the planes of the same block so that they share an XCD's L2.
+// The workgroups are persistent and pull streams from an atomic queue, most significant byte planes first
+// (the hardware places workgroups statically: with one stream per workgroup some CUs got only slow planes).
 //
 //   phase A  the wave reads its block with 16-byte coalesced loads and keeps byte plane s in LDS
 //            (the byte-shuffle filter, fused with the stream split).
@@ -21,9 +22,11 @@
 //                a slot collision): lanes <= B see exactly the table a sequential scan would show
 //                them; heads > B put their old slot value back,
 //              - a match at lane B is extended backwards and forwards with lane-parallel compares
-//                (one LDS round trip for both) and emitted with lane-parallel literal copies; the
-//                "probe right after the match" of the sequential algorithm rides as lane 0 of the
-//                next window.
+//                (one LDS round trip for both); the "probe right after the match" of the sequential
+//                algorithm rides as lane 0 of the next window.
+//            In front of the windows sit three cheaper paths for what compressible data mostly needs (DESIGN.md
+//            section 4): the scalar head (post-match probe + first two probes from 10 bytes in scalars), the
+//            run path and the narrow path.  Found sequences are parked in lanes and written 64 at a time.
 //            Output goes to the block's scratch slot; a per-stream record (kind, size, need) is left
 //            for the layout kernel.  `need` is the smallest output budget under which LZ4 still
 //            succeeds; it lets the layout kernel re-apply blosc2's running-destsize rule without
