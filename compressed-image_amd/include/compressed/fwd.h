@@ -1,7 +1,3 @@
+// fwd.h -- kept for source compatibility; everything lives in detail/config.h
 #pragma once
-#include "macros.h"
-namespace NAMESPACE_COMPRESSED_IMAGE
-{
-	template <typename T> struct channel;
-	template <typename T> struct image;
-}
+#include "detail/config.h"
