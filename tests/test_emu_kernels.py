@@ -201,3 +201,37 @@ def test_unusual_typesizes():
             assert cb[0] == r and chunks[0] == c, (ts, blocksize)
             rc, st, outs = E.decompress_batch([chunks[0]], sizes, [O.cbuffer_sizes(c)[2]], misalign=1)
             assert rc == 0 and not any(st) and outs[0].tobytes() == raw.tobytes()
+
+
+def test_randomized_geometries_against_the_oracle():
+    """The seeded differential test of tests/test_gpu_parity.py on the emulated kernels (fewer rounds), cycling
+    through the three colliding-write orders."""
+    from test_gpu_parity import _mixed_data
+    rng = np.random.default_rng(20260102)
+    for it in range(40):
+        ts = int(rng.choice([1, 2, 2, 4, 4, 8, 3]))
+        blocksize = int(rng.choice([256, 1024, 4096, 8192, 32768])) // ts * ts
+        chunk = min(int(rng.integers(1, 6)) * blocksize + (int(rng.integers(0, blocksize)) // ts * ts if rng.random() < 0.4 else 0), 120000) // ts * ts or ts
+        total = max(chunk * int(rng.integers(0, 3)) + int(rng.integers(1, chunk + 1)) // ts * ts, ts)
+        raw = _mixed_data(rng, total, ts)
+        filt = int(rng.choice([0, 1, 1, 1, 2]))
+        dest = chunk + 32 if rng.random() < 0.7 else max(40, int(chunk * rng.uniform(0.3, 1.0)))
+        sizes = [min(chunk, total - o) for o in range(0, total, chunk)]
+        E.set_write_order(it % 3)
+        try:
+            rc, cb, chunks = E.compress_batch(E.cparams(ts, blocksize=blocksize, filters=(0, 0, 0, 0, 0, filt)), raw, sizes, [dest] * len(sizes))
+        finally:
+            E.set_write_order(0)
+        assert rc == 0
+        po = O.cparams(ts, blocksize=blocksize, filters=(0, 0, 0, 0, 0, filt))
+        off = 0
+        for i, s in enumerate(sizes):
+            r, want = O.compress(po, raw[off:off + s], destsize=dest)
+            assert cb[i] == r and chunks[i] == want, (it, i, ts, blocksize, chunk, filt, dest)
+            off += s
+        live = [(c, s) for c, s in zip(chunks, sizes) if len(c)]
+        if live:
+            rc, st, outs = E.decompress_batch([c for c, _ in live], [s for _, s in live], [O.cbuffer_sizes(c)[2] for c, _ in live], misalign=it % 4)
+            assert rc == 0 and not any(st)
+            want = b"".join(raw[sum(sizes[:i]):sum(sizes[:i + 1])].tobytes() for i, c in enumerate(chunks) if len(c))
+            assert b"".join(o.tobytes() for o in outs) == want

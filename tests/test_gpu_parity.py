@@ -374,3 +374,75 @@ def test_unusual_typesizes(eng):
             assert len(c) == r and c == want, (ts, blocksize)
             outs, st = eng.decompress_host([c])
             assert not st.any() and outs[0].tobytes() == raw.tobytes()
+
+
+def _mixed_data(rng, n, ts):
+    """n bytes of ts-byte elements: smooth ramps, flat runs, noise and repeats glued together at random."""
+    out = np.empty(n, np.uint8)
+    ne = n // ts
+    e = np.zeros((ne, ts), np.uint8)
+    pos = 0
+    while pos < ne:
+        ln = int(rng.integers(1, 4000))
+        kind = int(rng.integers(0, 5))
+        seg = e[pos:pos + ln]
+        m = seg.shape[0]
+        if kind == 0:
+            seg[:] = rng.integers(0, 256, (m, ts), dtype=np.uint8)
+        elif kind == 1:
+            seg[:] = rng.integers(0, 256, (1, ts), dtype=np.uint8)
+        elif kind == 2:
+            ramp = (np.arange(m) // int(rng.integers(1, 40))).astype(np.uint32) * int(rng.integers(1, 300))
+            for b in range(ts):
+                seg[:, b] = (ramp >> (8 * (b % 4))) & 0xFF
+        elif kind == 3 and pos > 0:
+            back = int(rng.integers(1, min(pos, 5000) + 1))
+            src = e[pos - back:pos - back + m]
+            seg[:src.shape[0]] = src
+        else:
+            seg[:, 0] = rng.integers(0, 4, m, dtype=np.uint8)
+            seg[:, 1:] = 7
+        pos += ln
+    out[:ne * ts] = e.ravel()
+    out[ne * ts:] = 1
+    return out
+
+
+def test_randomized_geometries_against_the_oracle(eng):
+    """Seeded differential test: random element size, block size, chunk size, clevel, filter, dest capacity and data
+    make-up; every chunk must equal the oracle's byte for byte and decode back to the input."""
+    rng = np.random.default_rng(20260101)
+    for it in range(400):
+        ts = int(rng.choice([1, 2, 2, 4, 4, 8, 3]))
+        blocksize = int(rng.choice([256, 1024, 4096, 8192, 32768, 65536])) // ts * ts
+        nchunks = int(rng.integers(1, 5))
+        chunk = int(rng.integers(1, 9)) * blocksize + (int(rng.integers(0, blocksize)) // ts * ts if rng.random() < 0.4 else 0)
+        chunk = min(chunk, 300000) // ts * ts or ts
+        total = chunk * (nchunks - 1) + int(rng.integers(1, chunk + 1)) // ts * ts
+        total = max(total, ts)
+        raw = _mixed_data(rng, total, ts)
+        clevel = int(rng.choice([1, 5, 9, 9, 9]))
+        filt = int(rng.choice([0, 1, 1, 1, 2]))
+        if filt == 2 and blocksize > 65536 // 1:
+            filt = 1
+        dest = chunk + 32 if rng.random() < 0.7 else max(40, int(chunk * rng.uniform(0.3, 1.0)))
+        sizes = [min(chunk, total - o) for o in range(0, total, chunk)]
+        p = hip.cparams(ts, clevel=clevel, blocksize=blocksize, filters=(0, 0, 0, 0, 0, filt))
+        po = O.cparams(ts, clevel=clevel, blocksize=blocksize, filters=(0, 0, 0, 0, 0, filt))
+        chunks = eng.compress_host(p, raw, sizes, [dest] * len(sizes))
+        off = 0
+        for i, s in enumerate(sizes):
+            r, want = O.compress(po, raw[off:off + s], destsize=dest)
+            assert len(chunks[i]) == max(r, 0) and chunks[i] == want, (it, i, ts, blocksize, chunk, clevel, filt, dest, len(chunks[i]), r)
+            off += s
+        live = [(c, s) for c, s in zip(chunks, sizes) if c]
+        if live:
+            outs, status = eng.decompress_host([c for c, _ in live])
+            assert not status.any(), (it, status)
+            off = 0
+            k = 0
+            for i, s in enumerate(sizes):
+                if chunks[i]:
+                    assert outs[k].tobytes() == raw[off:off + s].tobytes(), (it, i)
+                    k += 1
+                off += s
