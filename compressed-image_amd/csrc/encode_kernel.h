@@ -237,6 +237,8 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
         int sstart = 1;     // search start position
         int t0 = 0;         // probes of this search already committed
         int pre = 0;        // 1: lane 0 is the probe right after a match (position sstart - 1)
+        LV<uint32_t> Wn;    // bytes [ip - 2, ip + 10) around the end of the last match, lanes 0..2 (scalar head)
+        FOR_LANES(l) { Wn[l] = 0; }
         int guard = 0;      // every wave must reach an exit: a window commits at least one probe, so n + 2 windows is a hard bound
         for (;;) {
             if (++guard > n + 2) return -1;
@@ -335,9 +337,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             if (pre && dense && mflimit_p1 - sstart >= 3) {
                 headed = true;
                 const int ip0 = sstart - 1;
-                LV<uint32_t> W;
-                FOR_LANES(l) { W[l] = lds_ld32u(in, ip0 - 2 + 4 * (l < 2 ? l : 2)); }
-                const uint32_t w0 = readlane(W, 0), w1 = readlane(W, 1);
+                const uint32_t w0 = readlane(Wn, 0), w1 = readlane(Wn, 1);     // requested when the previous match was parked
                 const uint32_t v0 = (w0 >> 16) | (w1 << 16), v1 = (w0 >> 24) | (w1 << 8), v2 = w1;   // bytes at ip0, ip0 + 1, ip0 + 2
                 CIMG_PROF_LAP(1);
                 if (v0 == v1) {
@@ -573,6 +573,9 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);               // match extension
             ip -= backrun; mp -= backrun; mcode += backrun;
             const int lit = zero_lit ? 0 : ip - anchor;
+            // the ten bytes the scalar head of the NEXT search needs sit at the end of this match: request them now, so
+            // that the LDS round trip runs behind the bookkeeping below instead of in front of the next search
+            FOR_LANES(l) { Wn[l] = lds_ld32u(in, ip + mcode + 4 - 2 + 4 * (l < 2 ? l : 2)); }
             // ---- park the sequence; budget checks and stores happen 64 sequences at a time -------------------
             {
                 const int slot = np;
