@@ -450,7 +450,9 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
             e->enc_wgs_lds[split] = lds_bytes;
             if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] encode launch: %d bytes LDS -> %d workgroups per CU x %d CUs\n", lds_bytes, per_cu, e->num_cus);
         }
-        const int grid = std::min(items, e->enc_wgs_per_cu[split] * e->num_cus);
+        int per_cu_use = e->enc_wgs_per_cu[split];
+        if (const char* o = getenv("CIMG_ENC_WGS_PER_CU")) per_cu_use = std::max(1, std::min(per_cu_use, atoi(o)));   // diagnostic: fewer resident workgroups
+        const int grid = std::min(items, per_cu_use * e->num_cus);
         if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_streams, ea, grid, 64, lds_bytes))) return rc;
     }
     AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
