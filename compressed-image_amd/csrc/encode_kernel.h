@@ -636,14 +636,19 @@ CIMG_DEV bool plane_is_run(const uint8_t* in, int n, uint32_t& value)
     FOR_LANES(l) { first[l] = in[0]; }
     value = readlane(first, 0);
     const uint32_t w = value * 0x01010101u;
-    const int words = n >> 2;
-    for (int c = 0; c < words; c += 64) {
+    // 1 KiB per step (16 bytes per lane); almost every plane leaves at the first step, constant channels (alpha,
+    // masks) run through all of them
+    const int units = n >> 4;
+    for (int c = 0; c < units; c += 64) {
         LV<bool> bad;
-        FOR_LANES(l) { bad[l] = c + l < words && *reinterpret_cast<const uint32_t*>(in + 4 * (c + l)) != w; }
+        FOR_LANES(l) {
+            const u128 q = ld128a(in + 16 * (c + l < units ? c + l : 0));
+            bad[l] = (c + l < units) & ((q.x != w) | (q.y != w) | (q.z != w) | (q.w != w));
+        }
         if (ballot(bad)) return false;
     }
     LV<bool> bad;
-    FOR_LANES(l) { bad[l] = 4 * words + l < n && in[4 * words + l] != (uint8_t)value; }
+    FOR_LANES(l) { bad[l] = 16 * units + l < n && in[16 * units + l] != (uint8_t)value; }
     return ballot(bad) == 0;
 }
 
