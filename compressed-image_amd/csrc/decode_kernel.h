@@ -138,7 +138,18 @@ CIMG_DEV void wave_fill_lds(uint8_t* lds, int off, int nbytes, uint32_t byte)
 CIMG_DEV void wave_copy_g2g(const uint8_t* src, uint8_t* dst, int nbytes, int wave, int nwaves)
 {
     const int units = nbytes >> 4;
-    for (int u0 = wave * 64; u0 < units; u0 += nwaves * 64) {
+    // four 16-byte loads per lane are in flight before the first store (a copy with one is pure HBM latency)
+    constexpr int DEPTH = 4;
+    const int stride = nwaves * 64;
+    int u0 = wave * 64;
+    for (; u0 + (DEPTH - 1) * stride + 64 <= units; u0 += DEPTH * stride) {
+        LV<u128> t[DEPTH];
+        CIMG_UNROLL
+        for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { t[k][l] = ld128u(src + 16 * (u0 + k * stride + l)); } }
+        CIMG_UNROLL
+        for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { st128u(dst + 16 * (u0 + k * stride + l), t[k][l]); } }
+    }
+    for (; u0 < units; u0 += stride) {
         LV<u128> t;
         FOR_LANES(l) { if (u0 + l < units) t[l] = ld128u(src + 16 * (u0 + l)); }
         FOR_LANES(l) { if (u0 + l < units) st128u(dst + 16 * (u0 + l), t[l]); }
