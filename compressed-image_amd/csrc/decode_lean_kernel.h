@@ -108,8 +108,35 @@ struct DecodeLean {
         }
         const int units = bsize >> 4;
         const int tid0 = wave * 64, step = nwaves * 64;
+        // The stored planes come from global memory: DEPTH units per lane are requested before the first is used
+        // (one wave per block has nothing else to hide HBM latency with).
+        constexpr int DEPTH = 8;
         if (ts == 2) {
-            for (int u0 = tid0; u0 < units; u0 += step) {
+            int u0 = tid0;
+            for (; u0 + (DEPTH - 1) * step + 64 <= units; u0 += DEPTH * step) {
+                LV<uint32_t> a0[DEPTH], a1[DEPTH], b0[DEPTH], b1[DEPTH];
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) {
+                    FOR_LANES(l) {
+                        const int u = u0 + k * step + l;
+                        a0[k][l] = plane_word(0, 8 * u); a1[k][l] = plane_word(0, 8 * u + 4);
+                        b0[k][l] = plane_word(1, 8 * u); b1[k][l] = plane_word(1, 8 * u + 4);
+                    }
+                }
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) {
+                    FOR_LANES(l) {
+                        const int u = u0 + k * step + l;
+                        u128 o;
+                        o.x = byte_perm(b0[k][l], a0[k][l], 0x05010400u);
+                        o.y = byte_perm(b0[k][l], a0[k][l], 0x07030602u);
+                        o.z = byte_perm(b1[k][l], a1[k][l], 0x05010400u);
+                        o.w = byte_perm(b1[k][l], a1[k][l], 0x07030602u);
+                        st128u(out + 16 * u, o);
+                    }
+                }
+            }
+            for (; u0 < units; u0 += step) {
                 FOR_LANES(l) {
                     const int u = u0 + l;
                     if (u < units) {
@@ -125,7 +152,32 @@ struct DecodeLean {
                 }
             }
         } else {
-            for (int u0 = tid0; u0 < units; u0 += step) {
+            int u0 = tid0;
+            for (; u0 + (DEPTH - 1) * step + 64 <= units; u0 += DEPTH * step) {
+                LV<uint32_t> A[DEPTH], B[DEPTH], C[DEPTH], D[DEPTH];
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) {
+                    FOR_LANES(l) {
+                        const int u = u0 + k * step + l;
+                        A[k][l] = plane_word(0, 4 * u); B[k][l] = plane_word(1, 4 * u); C[k][l] = plane_word(2, 4 * u); D[k][l] = plane_word(3, 4 * u);
+                    }
+                }
+                CIMG_UNROLL
+                for (int k = 0; k < DEPTH; k++) {
+                    FOR_LANES(l) {
+                        const int u = u0 + k * step + l;
+                        const uint32_t t0 = byte_perm(B[k][l], A[k][l], 0x05010400u), t1 = byte_perm(B[k][l], A[k][l], 0x07030602u);
+                        const uint32_t v0 = byte_perm(D[k][l], C[k][l], 0x05010400u), v1 = byte_perm(D[k][l], C[k][l], 0x07030602u);
+                        u128 o;
+                        o.x = byte_perm(v0, t0, 0x05040100u);
+                        o.y = byte_perm(v0, t0, 0x07060302u);
+                        o.z = byte_perm(v1, t1, 0x05040100u);
+                        o.w = byte_perm(v1, t1, 0x07060302u);
+                        st128u(out + 16 * u, o);
+                    }
+                }
+            }
+            for (; u0 < units; u0 += step) {
                 FOR_LANES(l) {
                     const int u = u0 + l;
                     if (u < units) {
