@@ -73,50 +73,66 @@ struct LayoutChunk {
             const int nfull = d.leftover ? d.nblocks - 1 : d.nblocks;
             const int per_full = d.split ? ts : 1;
             const int total = nfull * per_full + (d.leftover ? 1 : 0);
-            for (int i0 = 0; i0 < total && fits; i0 += 64) {
-                LV<int> sz, pre;
-                LV<bool> bad, first;
-                LV<int> blk;
-                FOR_LANES(l) {
-                    const int i = i0 + l;
-                    sz[l] = 0; bad[l] = false; first[l] = false; blk[l] = 0;
-                    if (i < total) {
+            // records of GROUP tiles (64 streams each) are requested before the first tile is looked at: one wave per
+            // chunk has nothing else to hide the load latency with
+            constexpr int GROUP = 4;
+            for (int g0 = 0; g0 < total && fits; g0 += 64 * GROUP) {
+                LV<StreamRec> recs[GROUP];
+                CIMG_UNROLL
+                for (int k = 0; k < GROUP; k++) {
+                    FOR_LANES(l) {
+                        const int i = imin(g0 + 64 * k + l, total - 1);
                         int jb, s;
                         if (i < nfull * per_full) { jb = i / per_full; s = i - jb * per_full; } else { jb = nfull; s = 0; }
-                        const StreamRec r = a.recs[(int64_t)(d.blk0 + jb) * a.p.streams_per_block + s];
-                        sz[l] = 4 + rec_payload(r);
-                        first[l] = s == 0;
-                        blk[l] = jb;
+                        recs[k][l] = a.recs[(int64_t)(d.blk0 + jb) * a.p.streams_per_block + s];
                     }
                 }
-                int tile_total;
-                wave_exscan(sz, pre, tile_total);
-                FOR_LANES(l) {
-                    const int i = i0 + l;
-                    if (i < total) {
-                        int jb, s;
-                        if (i < nfull * per_full) { jb = i / per_full; s = i - jb * per_full; } else { jb = nfull; s = 0; }
-                        const StreamRec r = a.recs[(int64_t)(d.blk0 + jb) * a.p.streams_per_block + s];
-                        const int bsize = (jb == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
-                        const int neblock = bsize / ((d.split && !(jb == d.nblocks - 1 && d.leftover)) ? ts : 1);
-                        const int N = nt + pre[l] + 4;               // offset right after this stream's csize word
-                        bool f = false;
-                        if (r.kind == REC_RUN) {
-                            f = N > d.destsize || (r.value > 0 && N + 1 > d.destsize);
-                        } else {
-                            int maxout = neblock;
-                            if (N + maxout > d.destsize) { maxout = d.destsize - N; if (maxout <= 0) f = true; }
-                            if (!f) {
-                                if (r.kind == REC_LZ4) { if (r.need > maxout) f = true; }
-                                else if (N + neblock > d.destsize) f = true;
-                            }
+                CIMG_UNROLL
+                for (int k = 0; k < GROUP; k++) {
+                    const int i0 = g0 + 64 * k;
+                    if (i0 >= total || !fits) break;
+                    LV<int> sz, pre;
+                    LV<bool> bad, first;
+                    LV<int> blk;
+                    FOR_LANES(l) {
+                        const int i = i0 + l;
+                        sz[l] = 0; bad[l] = false; first[l] = false; blk[l] = 0;
+                        if (i < total) {
+                            int jb, s;
+                            if (i < nfull * per_full) { jb = i / per_full; s = i - jb * per_full; } else { jb = nfull; s = 0; }
+                            sz[l] = 4 + rec_payload(recs[k][l]);
+                            first[l] = s == 0;
+                            blk[l] = jb;
                         }
-                        bad[l] = f;
-                        if (first[l]) st32(c + HEADER_LEN + 4 * blk[l], nt + pre[l]);
                     }
+                    int tile_total;
+                    wave_exscan(sz, pre, tile_total);
+                    FOR_LANES(l) {
+                        const int i = i0 + l;
+                        if (i < total) {
+                            const int jb = blk[l];
+                            const StreamRec r = recs[k][l];
+                            const int bsize = (jb == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
+                            const int neblock = bsize / ((d.split && !(jb == d.nblocks - 1 && d.leftover)) ? ts : 1);
+                            const int N = nt + pre[l] + 4;               // offset right after this stream's csize word
+                            bool f = false;
+                            if (r.kind == REC_RUN) {
+                                f = N > d.destsize || (r.value > 0 && N + 1 > d.destsize);
+                            } else {
+                                int maxout = neblock;
+                                if (N + maxout > d.destsize) { maxout = d.destsize - N; if (maxout <= 0) f = true; }
+                                if (!f) {
+                                    if (r.kind == REC_LZ4) { if (r.need > maxout) f = true; }
+                                    else if (N + neblock > d.destsize) f = true;
+                                }
+                            }
+                            bad[l] = f;
+                            if (first[l]) st32(c + HEADER_LEN + 4 * blk[l], nt + pre[l]);
+                        }
+                    }
+                    if (ballot(bad)) fits = false;
+                    nt += tile_total;
                 }
-                if (ballot(bad)) fits = false;
-                nt += tile_total;
             }
             if (fits) {
                 if (nt == HEADER_LEN + 4 * d.nblocks + 4 * total) {
