@@ -18,7 +18,7 @@
  *       csize == 0         -> stream is all zero bytes, no payload
  *       csize  < 0         -> stream is a run of byte (-csize); one token byte 0x01 follows
  *       csize == streamlen -> payload stored raw
- *       otherwise          -> LZ4 block
+ *       otherwise          -> LZ4 block (codec format 1: lz4, lz4hc) or BloscLZ stream (codec format 0)
  */
 #include "orc.h"
 #include <stdlib.h>
@@ -153,7 +153,8 @@ static const uint8_t* filters_forward(const orc_cparams* p, int ts, int bsize, c
 static int codec_compress(const orc_cparams* p, const uint8_t* s, int n, uint8_t* d, int maxout, int* need)
 {
     if (p->compcode == ORC_LZ4) return orc_lz4_compress_fast(s, n, d, maxout, 10 - p->clevel, need);
-    return ORC_ERR_CODEC_SUPPORT;
+    if (p->compcode == ORC_BLOSCLZ) return orc_blosclz_compress(p->clevel, s, n, d, maxout, need);
+    return ORC_ERR_CODEC_SUPPORT;          /* lz4hc / zstd encoders are not restated (their chunks still decode) */
 }
 
 /* one block, written at dst (= chunk + ntbytes).  Returns block bytes, 0 = does not fit, <0 error. */
@@ -270,7 +271,7 @@ int orc_blosc2_compress_2phase(const orc_cparams* p, const void* src_, int32_t n
     const int ts = p->typesize > MAX_TYPESIZE ? 1 : p->typesize;
     write_header(p, &g, nbytes, dst);
     if (g.memcpyed) return finish_memcpyed(&g, src, nbytes, dst, destsize);
-    if (compformat_of(p->compcode) != 1 || p->compcode != ORC_LZ4) return ORC_ERR_CODEC_SUPPORT;
+    if (p->compcode != ORC_LZ4 && p->compcode != ORC_BLOSCLZ) return ORC_ERR_CODEC_SUPPORT;
 
     const int maxstreams = g.split ? ts : 1;
     const size_t slot = (size_t)g.blocksize + 16;
@@ -296,8 +297,7 @@ int orc_blosc2_compress_2phase(const orc_cparams* p, const void* src_, int32_t n
             const uint8_t* sp = fdst + (size_t)s * neblock;
             if (all_equal(sp, neblock)) { r->kind = 0; r->value = sp[0]; continue; }
             int need = 0;
-            int cb = orc_lz4_compress_fast(sp, neblock, scratch + (size_t)j * slot + (size_t)s * neblock,
-                                           neblock, 10 - p->clevel, &need);
+            int cb = codec_compress(p, sp, neblock, scratch + (size_t)j * slot + (size_t)s * neblock, neblock, &need);
             if (cb < 0) { err = cb; continue; }
             if (cb == 0 || cb == neblock) { r->kind = 2; r->csize = neblock; }
             else { r->kind = 1; r->csize = cb; r->need = need; }
@@ -394,7 +394,7 @@ int orc_blosc2_decompress(const void* src_, int32_t srcsize, void* dst_, int32_t
         return nbytes;
     }
     const int compformat = flags >> 5;
-    if (compformat != 1) return ORC_ERR_CODEC_SUPPORT;
+    if (compformat != 0 && compformat != 1) return ORC_ERR_CODEC_SUPPORT;   /* blosclz; lz4 and lz4hc share format 1 */
     const int dont_split = (flags & FLAG_DONT_SPLIT) != 0;
     int nblocks = nbytes / blocksize;
     const int leftover = nbytes % blocksize;
@@ -428,7 +428,8 @@ int orc_blosc2_decompress(const void* src_, int32_t srcsize, void* dst_, int32_t
             }
             if (cs > left) { rc = ORC_ERR_READ_BUFFER; goto done; }
             if (cs == neblock) memcpy(out, ip, (size_t)neblock);
-            else if (orc_lz4_decompress_safe(ip, cs, out, neblock) != neblock) { rc = ORC_ERR_DATA; goto done; }
+            else if ((compformat == 1 ? orc_lz4_decompress_safe(ip, cs, out, neblock)
+                                      : orc_blosclz_decompress(ip, cs, out, neblock)) != neblock) { rc = ORC_ERR_DATA; goto done; }
             ip += cs; left -= cs;
         }
         /* backward filter pipeline */

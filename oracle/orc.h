@@ -52,7 +52,7 @@ typedef struct {
     int32_t clevel;      /* 0..9 */
     int32_t typesize;    /* sizeof(T) */
     int32_t blocksize;   /* requested block size in bytes (0 unsupported: the reference always sets it) */
-    int32_t compcode;    /* ORC_LZ4 (ORC_BLOSCLZ once restated) */
+    int32_t compcode;    /* ORC_LZ4 or ORC_BLOSCLZ (lz4hc / zstd: decode of format 1 only, no encoder restated) */
     int32_t splitmode;   /* ORC_AUTO_SPLIT is what the reference uses (wrapper.h:328,353) */
     uint8_t filters[ORC_MAX_FILTERS];      /* default {0,0,0,0,0,ORC_SHUFFLE} */
     uint8_t filters_meta[ORC_MAX_FILTERS];
@@ -67,6 +67,15 @@ void orc_cparams_default(orc_cparams* p);
 int orc_lz4_compress_fast(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, int* need);
 /* Strict LZ4 block decoder: returns decoded size or <0. */
 int orc_lz4_decompress_safe(const uint8_t* src, int csize, uint8_t* dst, int cap);
+
+/* ---- BloscLZ stream layer (blosclz.c) ---- */
+/* Byte-for-byte behaviour of blosclz_compress(clevel, src, n, dst, cap) of BloscLZ 2.3.0 (see blosclz.c for
+ * what that pin means).  Returns compressed size, 0 if not worth it / does not fit.  *need as for LZ4. */
+int orc_blosclz_compress(int clevel, const uint8_t* src, int n, uint8_t* dst, int cap, int* need);
+int orc_blosclz_decompress(const uint8_t* src, int csize, uint8_t* dst, int cap);
+/* the encoder's entropy probe, exposed for tests: counted bytes of the dry run / chosen ipshift (0 = give up) */
+int orc_blosclz_probe(const uint8_t* src, int maxlen, int force_3b_shift);
+int orc_blosclz_plan(int clevel, const uint8_t* src, int n);
 
 /* ---- filters (filters.c) ---- */
 void orc_shuffle(int typesize, int bsize, const uint8_t* src, uint8_t* dst);

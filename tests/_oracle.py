@@ -51,6 +51,14 @@ def lib():
         L.orc_lz4_compress_fast.restype = C.c_int
         L.orc_lz4_decompress_safe.argtypes = [u8p, C.c_int, u8p, C.c_int]
         L.orc_lz4_decompress_safe.restype = C.c_int
+        L.orc_blosclz_compress.argtypes = [C.c_int, u8p, C.c_int, u8p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_blosclz_compress.restype = C.c_int
+        L.orc_blosclz_decompress.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        L.orc_blosclz_decompress.restype = C.c_int
+        L.orc_blosclz_probe.argtypes = [u8p, C.c_int, C.c_int]
+        L.orc_blosclz_probe.restype = C.c_int
+        L.orc_blosclz_plan.argtypes = [C.c_int, u8p, C.c_int]
+        L.orc_blosclz_plan.restype = C.c_int
         for n in ("orc_shuffle", "orc_unshuffle", "orc_bitshuffle", "orc_bitunshuffle"):
             getattr(L, n).argtypes = [C.c_int, C.c_int, u8p, u8p]
             getattr(L, n).restype = None
@@ -103,6 +111,29 @@ def lz4_decompress(comp, n):
     out = np.zeros(max(n, 1), dtype=np.uint8)
     r = lib().orc_lz4_decompress_safe(_ptr(c), c.size, _ptr(out), n)
     return r, out[:max(r, 0)].tobytes()
+
+
+def blosclz_compress(src, clevel=9, cap=None, want_need=False):
+    s = _bytes_in(src)
+    n = s.size
+    cap = n if cap is None else cap
+    out = np.zeros(max(cap, n) + 64, dtype=np.uint8)
+    need = C.c_int(0)
+    r = lib().orc_blosclz_compress(clevel, _ptr(s), n, _ptr(out), cap, C.byref(need))
+    data = out[:max(r, 0)].tobytes()
+    return (r, data, need.value) if want_need else (r, data)
+
+
+def blosclz_decompress(comp, n):
+    c = _bytes_in(comp)
+    out = np.zeros(max(n, 1) + 8, dtype=np.uint8)
+    r = lib().orc_blosclz_decompress(_ptr(c), c.size, _ptr(out), n)
+    return r, out[:max(r, 0)].tobytes()
+
+
+def blosclz_plan(src, clevel=9):
+    s = _bytes_in(src)
+    return lib().orc_blosclz_plan(clevel, _ptr(s), s.size)
 
 
 def _filter(fn, ts, data):

@@ -5,6 +5,7 @@ No reference test pins compressed bytes, so the framing assertions below restate
 c-blosc2 chunk format; they are the "self-generated, unverified vs
 c-blosc2" layer of the parity story ("Parity status").
 """
+import os
 import struct
 
 import numpy as np
@@ -215,3 +216,14 @@ def test_decoder_flags_corruption():
     bad = bytearray(c)
     struct.pack_into("<i", bad, 32, len(c) + 100)           # bstart outside the chunk
     assert O.decompress(bytes(bad), a.nbytes)[0] < 0
+
+
+def test_lz4hc_chunks_decode(golden_dir):
+    """lz4hc is codec format 1 = plain LZ4 blocks: chunks coded by liblz4's LZ4_compress_HC (tests/golden/
+    make_lz4hc_golden.py) decode through the ordinary path (enums.h:18-24 lists lz4hc as a valid codec)."""
+    kat = np.load(os.path.join(golden_dir, "lz4hc_kat.npz"))
+    for name in kat["cases"]:
+        chunk, src = kat["chunk|" + str(name)], kat["in|" + str(name)]
+        assert chunk[22] == O.LZ4HC and (chunk[2] >> 5) == 1 and chunk[2] & 0x10
+        n, pix = O.decompress(chunk)
+        assert n == src.size and pix.tobytes() == src.tobytes(), name
