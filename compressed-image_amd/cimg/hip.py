@@ -21,7 +21,7 @@ MAX_OVERHEAD = 32
 EXPORTS = (
     # include/cimg_hip.h
     "cimg_cparams_init", "cimg_engine_create", "cimg_engine_destroy", "cimg_last_error",
-    "cimg_engine_synchronize", "cimg_engine_stream", "cimg_compress_batch_device",
+    "cimg_engine_synchronize", "cimg_engine_lock", "cimg_engine_unlock", "cimg_engine_stream", "cimg_compress_batch_device",
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host",
     "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",

@@ -47,12 +47,16 @@ CIMG_HD int round16(int x) { return (x + 15) & ~15; }
 // the in-place write pointer behind the read pointer for every valid LZ4 block
 CIMG_HD int inplace_margin(int n) { return round16(n / 255) + 64; }
 CIMG_HD int region_stride(int neblock) { return round16(neblock) + inplace_margin(neblock); }
+// the same for a BloscLZ stream (blosclz_kernel.h): one control byte per 32 literals
+CIMG_HD int blz_inplace_margin(int n) { return round16(n / 32 + 1) + 64; }
+CIMG_HD int blz_region_stride(int neblock) { return round16(neblock) + blz_inplace_margin(neblock); }
+// LDS of one block workgroup; sized for the codec with the larger margin (the host does not look at the codec bits)
 inline int decode_lds_bytes(int blocksize, int typesize)
 {
-    int a = round16(blocksize) + inplace_margin(blocksize);
+    int a = blz_region_stride(blocksize);
     if (typesize >= 1 && typesize <= MAX_STREAMS) {
         const int ne = blocksize / typesize;
-        const int b = typesize * (round16(ne) + inplace_margin(ne));
+        const int b = typesize * blz_region_stride(ne);
         if (b > a) a = b;
     }
     return a + 32;
@@ -597,6 +601,9 @@ inline uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
 CIMG_DEV uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 #endif
 
+// blosclz_kernel.h (included behind this header: it uses the copy helpers above)
+CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, int lds_limit);
+
 // ---- the kernel body ---------------------------------------------------------------------------------
 struct DecodeBlock {
     const DecodeArgs& a;
@@ -641,7 +648,8 @@ struct DecodeBlock {
             wave_copy_g2g(c + HEADER_LEN + (int64_t)j * blocksize, out, bsize, wave, 4);
             return;
         }
-        if ((flags >> 5) != 1) { fail(ERR_CODEC_SUPPORT); return; }
+        const int fmt = flags >> 5;                                  // 0 blosclz, 1 lz4 / lz4hc
+        if (fmt != 0 && fmt != 1) { fail(ERR_CODEC_SUPPORT); return; }
         // filter pipeline: exactly one of {none, shuffle, bitshuffle}, in the last slot
         filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0) { fail(ERR_CODEC_SUPPORT); return; }
@@ -650,7 +658,7 @@ struct DecodeBlock {
         const bool leftover_blk = bsize != blocksize;
         ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
         neblock = bsize / ns;
-        rs = region_stride(neblock);
+        rs = fmt == 0 ? blz_region_stride(neblock) : region_stride(neblock);
         if (ns * rs + 16 > a.lds_bytes) { fail(ERR_FAILURE); return; }
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { fail(ERR_DATA); return; }
@@ -678,7 +686,8 @@ struct DecodeBlock {
                 } else {
                     const int park = base + rs - round16(cs);
                     wave_copy_g2l(c + pos, lds, park, cs);
-                    const int rc = lz4_decode_wave(lds, base, neblock, park, cs, a.lds_bytes, a.dbg, b);
+                    const int rc = fmt == 0 ? blosclz_decode_wave(lds, base, neblock, park, cs, a.lds_bytes)
+                                            : lz4_decode_wave(lds, base, neblock, park, cs, a.lds_bytes, a.dbg, b);
                     if (rc < 0) fail(rc);
                 }
             }

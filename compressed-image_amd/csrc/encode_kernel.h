@@ -35,6 +35,7 @@
 #include "codec_types.h"
 #include "wave.h"
 #include "decode_kernel.h"   // round16, find_chunk, byte_perm, wave copies
+#include "blosclz_kernel.h"
 
 namespace cimg {
 
@@ -56,7 +57,10 @@ struct EncodeArgs {
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
 
 // LDS of one stream workgroup: the plane (padded to 16), then the hash table
-inline int encode_lds_bytes(int stream_bytes) { return round16(stream_bytes) + LZ4_HASH_BYTES; }
+inline int encode_lds_bytes(int stream_bytes, int compcode = CODEC_LZ4)
+{
+    return compcode == CODEC_BLOSCLZ ? blz_encode_lds_bytes(stream_bytes) : round16(stream_bytes) + LZ4_HASH_BYTES;
+}
 // Work items of a launch.  Streams differ in cost by an order of magnitude and the hardware places
 // workgroups on CUs round-robin, not first-free, so the launch is a set of persistent workgroups that
 // pull items from a queue.  Split launch: item i is plane (spb-1 - i / total_blocks) of block
@@ -662,7 +666,9 @@ CIMG_DEV void wave_copy_l2g(const uint8_t* lds, int off, uint8_t* g, int nbytes)
     FOR_LANES(l) { if (done + l < nbytes) g[done + l] = lds[off + done + l]; }
 }
 
-// one single-wave workgroup = one stream
+// one single-wave workgroup = one stream.  CODEC selects the stream codec at compile time: the two encoders live in
+// two kernels (merged into one, the scalar state of both pushed the LZ4 kernel from 38 to 84 spilled SGPRs)
+template <int CODEC>
 struct EncodeStream {
     const EncodeArgs& a;
     uint8_t* lds;
@@ -869,7 +875,9 @@ struct EncodeStream {
             r.kind = REC_RUN; r.value = (int32_t)value; r.csize = 0;
         } else {
             int need = 0;
-            const int cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, a.p.accel, &need, a.dbg, item);
+            int cb;
+            if constexpr (CODEC == CODEC_BLOSCLZ) cb = blosclz_encode_body(lds, lds + round16(neblock) + 16, neblock, out, neblock, a.p.clevel, need);
+            else cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, a.p.accel, &need, a.dbg, item);
             if (cb > 0 && cb < neblock) {
                 r.kind = REC_LZ4; r.csize = cb; r.need = need;
             } else {

@@ -24,7 +24,14 @@ using namespace cimg;
 extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    EncodeStream es(a, lds, (int)blockIdx.x);
+    EncodeStream<CODEC_LZ4> es(a, lds, (int)blockIdx.x);
+    es.run();
+}
+
+extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams_blosclz(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    EncodeStream<CODEC_BLOSCLZ> es(a, lds, (int)blockIdx.x);
     es.run();
 }
 
@@ -118,11 +125,12 @@ struct cimg_engine {
     int num_cus = 256;
     int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
     int enc_wgs_lds[2] = {-1, -1};
+    int enc_wgs_codec = -1;
     bool stamps = false;
     bool trace = getenv("CIMG_TRACE") != nullptr;
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
-    int max_dyn_lds[3] = {0, 0, 0};      // largest dynamic LDS already enabled for encode / decode
+    int max_dyn_lds[4] = {0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -327,6 +335,9 @@ int cimg_engine_synchronize(cimg_engine* e)
     return e->hip(q, "hipEventQuery");
 }
 
+void cimg_engine_lock(cimg_engine* e) { e->mu.lock(); }
+void cimg_engine_unlock(cimg_engine* e) { e->mu.unlock(); }
+
 void* cimg_device_malloc(cimg_engine* e, size_t bytes)
 {
     void* p = nullptr;
@@ -441,11 +452,15 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks};
-        if ((rc = e->allow_lds(cimg_encode_streams, 0, lds_bytes))) return rc;
+        const bool blz = plan.cp.compcode == CODEC_BLOSCLZ;
+        void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : cimg_encode_streams;
+        if ((rc = e->allow_lds(enc_kernel, blz ? 3 : 0, lds_bytes))) return rc;
         // persistent workgroups: as many as are resident at once, never more than there are items
-        if (e->enc_wgs_lds[split] != lds_bytes) {
+        if (e->enc_wgs_lds[split] != lds_bytes || e->enc_wgs_codec != plan.cp.compcode) {
             int per_cu = 0;
-            if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_encode_streams, 64, (size_t)lds_bytes), "occupancy query"))) return rc;
+            e->enc_wgs_lds[0] = e->enc_wgs_lds[1] = -1;
+            e->enc_wgs_codec = plan.cp.compcode;
+            if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_kernel, 64, (size_t)lds_bytes), "occupancy query"))) return rc;
             e->enc_wgs_per_cu[split] = per_cu > 0 ? per_cu : 1;
             e->enc_wgs_lds[split] = lds_bytes;
             if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] encode launch: %d bytes LDS -> %d workgroups per CU x %d CUs\n", lds_bytes, per_cu, e->num_cus);
@@ -453,7 +468,7 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
         int per_cu_use = e->enc_wgs_per_cu[split];
         if (const char* o = getenv("CIMG_ENC_WGS_PER_CU")) per_cu_use = std::max(1, std::min(per_cu_use, atoi(o)));   // diagnostic: fewer resident workgroups
         const int grid = std::min(items, per_cu_use * e->num_cus);
-        if ((rc = e->launch(CIMG_K_ENCODE, cimg_encode_streams, ea, grid, 64, lds_bytes))) return rc;
+        if ((rc = e->launch(CIMG_K_ENCODE, enc_kernel, ea, grid, 64, lds_bytes))) return rc;
     }
     AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
                     (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks,

@@ -122,7 +122,7 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
     int filter = 0;
     int rc = single_filter(p, &filter);
     if (rc < 0) return rc;
-    if (p.compcode != CODEC_LZ4) return ERR_CODEC_SUPPORT;     // blosclz/lz4hc/zstd: not built yet
+    if (p.compcode != CODEC_LZ4 && p.compcode != CODEC_BLOSCLZ) return ERR_CODEC_SUPPORT;   // lz4hc / zstd encoders: not on the GPU path (their chunks decode)
     CodecParams& cp = plan->cp;
     cp.typesize = p.typesize > 255 ? 1 : p.typesize;
     cp.clevel = p.clevel;
@@ -147,11 +147,11 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
         if (!d.memcpyed) {
             const int nfull = d.leftover ? d.nblocks - 1 : d.nblocks;
             const bool multi = d.split && cp.typesize > 1;        // full blocks are cut into several planes
-            if (multi && nfull > 0) plan->lds_split = imax(plan->lds_split, encode_lds_bytes(d.blocksize / cp.typesize));
-            if (!multi && nfull > 0) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.blocksize));
-            if (d.leftover) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.leftover));
+            if (multi && nfull > 0) plan->lds_split = imax(plan->lds_split, encode_lds_bytes(d.blocksize / cp.typesize, p.compcode));
+            if (!multi && nfull > 0) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.blocksize, p.compcode));
+            if (d.leftover) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.leftover, p.compcode));
             const int stream_max = multi ? imax(nfull > 0 ? d.blocksize / cp.typesize : 0, d.leftover) : d.blocksize;
-            if (stream_max > LZ4_MAX_INPUT_U16) return ERR_CODEC_SUPPORT;   // byU32 LZ4 regime: not built
+            if (stream_max > (p.compcode == CODEC_BLOSCLZ ? BLZ_MAX_INPUT : LZ4_MAX_INPUT_U16)) return ERR_CODEC_SUPPORT;   // 32-bit position tables: not built
         }
     }
     if (plan->lds_split > MAX_LDS_BYTES || plan->lds_unsplit > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;

@@ -118,6 +118,11 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			p.clevel = compression_level;
 			p.nthreads = static_cast<int16_t>(nthreads == 0 ? 1 : nthreads);    // accepted, ignored: the parallelism is the GPU's
 			p.compcode = codec_to_blosc2(codec);
+			// fail where the choice is made, not at the first chunk: the MI355X path encodes lz4 and blosclz
+			// (lz4hc chunks written elsewhere still decode; zstd is not on the path at all)
+			if (codec == enums::codec::lz4hc || codec == enums::codec::zstd)
+				throw std::runtime_error(detail::text("codec ", codec == enums::codec::zstd ? "zstd" : "lz4hc",
+					" is not available for compression on the MI355X GPU path (available: lz4, blosclz)"));
 			return p;
 		}
 		template <typename T>
@@ -227,9 +232,15 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					nbytes[i] = static_cast<int32_t>(pieces[i].nbytes);
 					destsize[i] = static_cast<int32_t>(min_compressed_size(nominal_chunk_bytes));
 				}
-				// _begin and _fetch belong together: no other thread's batch may run on the shared engine in between
-				static std::mutex pair_mutex;
-				std::lock_guard<std::mutex> pair_lock(pair_mutex);
+				// _begin and _fetch belong together: the engine's own (recursive) lock is held across the pair, so no other
+				// user of the shared engine -- batch::decompress, the blosc2_*_ctx shim, another thread's compress -- can
+				// reuse its staging area in between
+				struct engine_guard
+				{
+					cimg_engine* e;
+					explicit engine_guard(cimg_engine* e_) : e(e_) { cimg_engine_lock(e); }
+					~engine_guard() { cimg_engine_unlock(e); }
+				} pair_lock(engine());
 				// step 1: upload + compress; the chunks stay on the device and their sizes come back
 				rc = cimg_compress_batch_host_begin(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(), destsize.data(), cbytes.data());
 				if (rc < 0)

@@ -8,10 +8,10 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 	{
 		enum class codec
 		{
-			blosclz,   // not built on the GPU path yet: requests fail with BLOSC2_ERROR_CODEC_SUPPORT
-			lz4,       // the GPU path
-			lz4hc,     // not built
-			zstd       // not built
+			blosclz,   // GPU encode + decode (bytes of BloscLZ 2.3.0, csrc/blosclz_kernel.h)
+			lz4,       // GPU encode + decode (the reference's default, channel.h:101)
+			lz4hc,     // decode only (codec format 1 = LZ4 blocks); compressing fails with BLOSC2_ERROR_CODEC_SUPPORT
+			zstd       // not on the GPU path: fails with BLOSC2_ERROR_CODEC_SUPPORT
 		};
 	}
 }

@@ -47,6 +47,10 @@ int  cimg_engine_create(int device, cimg_engine** out);      /* device < 0: curr
 void cimg_engine_destroy(cimg_engine* e);
 const char* cimg_last_error(const cimg_engine* e);            /* e may be NULL: last create() failure */
 int  cimg_engine_synchronize(cimg_engine* e);
+/* Every batch call takes the engine's (recursive) lock for its own duration.  A caller that needs two calls to act as
+ * one -- _begin followed by _fetch below -- brackets them with these, on the same thread. */
+void cimg_engine_lock(cimg_engine* e);
+void cimg_engine_unlock(cimg_engine* e);
 void* cimg_engine_stream(cimg_engine* e);                     /* the hipStream_t every launch goes to */
 
 /* ---- device-resident batches -----------------------------------------------------------------------

@@ -46,6 +46,10 @@ def lib():
         L.emu_lz4_encode.restype = C.c_int
         L.emu_lz4_decode.argtypes = [vp, C.c_int, vp, C.c_int]
         L.emu_lz4_decode.restype = C.c_int
+        L.emu_blosclz_encode.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.emu_blosclz_encode.restype = C.c_int
+        L.emu_blosclz_decode.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.emu_blosclz_decode.restype = C.c_int
         _lib = L
     return _lib
 
@@ -97,6 +101,23 @@ def lz4_decode(comp, n):
     c = _u8(comp)
     out = np.zeros(max(n, 1), np.uint8)
     r = lib().emu_lz4_decode(_p(c), c.size, _p(out), n)
+    return r, out[:n].tobytes()
+
+
+def blosclz_encode(src, cap=None, clevel=9):
+    s = _u8(src)
+    n = s.size
+    cap = n if cap is None else cap
+    out = np.full(max(cap, n) + 64, 0xAB, np.uint8)
+    need = C.c_int(0)
+    r = lib().emu_blosclz_encode(_p(s), n, _p(out), cap, clevel, C.byref(need))
+    return r, out[:max(r, 0)].tobytes(), need.value
+
+
+def blosclz_decode(comp, n):
+    c = _u8(comp)
+    out = np.zeros(max(n, 1), np.uint8)
+    r = lib().emu_blosclz_decode(_p(c), c.size, _p(out), n)
     return r, out[:n].tobytes()
 
 

@@ -70,9 +70,17 @@ static void channel_cases()
 		std::iota(d.begin(), d.end(), uint8_t{0});
 		channel<uint8_t> c(std::span<const uint8_t>(d), 10, 5);
 		CHECK(c.get_decompressed() == d);
-		// :74-87 attributes
-		CHECK(c.uncompressed_size() == 50 && c.num_chunks() == 1 && c.width() == 10 && c.height() == 5);
 		CHECK(c.compression() == enums::codec::lz4 && c.compression_level() == 9);
+	}
+	// test_channel.cpp:74-87 -- attributes of a blosclz channel
+	{
+		std::vector<uint8_t> d(50);
+		channel<uint8_t> c(std::span<const uint8_t>(d), 10, 5, enums::codec::blosclz, 9);
+		CHECK(c.width() == 10 && c.height() == 5);
+		CHECK(c.compression() == enums::codec::blosclz);
+		CHECK(c.compression_context() != nullptr && c.decompression_context() != nullptr);
+		CHECK(c.uncompressed_size() == 50 && c.num_chunks() == 1);
+		CHECK(c.get_decompressed() == d);
 	}
 	// test_channel.cpp:60-69 -- 8192 bytes, 128x64, lz4/9, block 128, chunk 4096 -> 2 chunks
 	{
@@ -227,6 +235,26 @@ static void thread_cases()
 	for (int t = 0; t < 4; ++t) pool.emplace_back(work, t);
 	for (auto& t : pool) t.join();
 	CHECK(bad.load() == 0);
+	// one thread only compresses (the two-step _begin / _fetch batch), another only decompresses an unrelated channel
+	// and a third uses the single-chunk blosc2_*_ctx calls: none may invalidate another's pending fetch
+	std::vector<uint8_t> base(40 * 50);
+	for (size_t i = 0; i < base.size(); ++i) base[i] = static_cast<uint8_t>(i / 9);
+	channel<uint8_t> shared(std::span<const uint8_t>(base), 40, 50, enums::codec::blosclz, 9, 256, 400);
+	std::atomic<int> errors{ 0 };
+	auto guarded = [&](auto&& fn) { return [&errors, fn] { try { for (int rep = 0; rep < 24; ++rep) fn(rep); } catch (const std::exception&) { ++errors; } }; };
+	std::thread tc(guarded([&](int rep) {
+		std::vector<uint16_t> d(64 * 32, static_cast<uint16_t>(rep));
+		channel<uint16_t> c(std::span<const uint16_t>(d), 64, 32, rep % 2 ? enums::codec::lz4 : enums::codec::blosclz, 9, 512, 1024);
+		if (c.num_chunks() != 4) ++errors;
+	}));
+	std::thread td(guarded([&](int) { if (shared.get_decompressed() != base) ++errors; }));
+	std::thread ts(guarded([&](int rep) {
+		std::vector<uint8_t> one(400);
+		shared.get_chunk(std::span<uint8_t>(one), static_cast<size_t>(rep % 5));
+		if (!std::equal(one.begin(), one.end(), base.begin() + 400 * (rep % 5))) ++errors;
+	}));
+	tc.join(); td.join(); ts.join();
+	CHECK(errors.load() == 0);
 }
 
 int main()

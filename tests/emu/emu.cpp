@@ -5,6 +5,7 @@
 #define CIMG_EMULATE 1
 #include "plan.h"
 #include "assemble_kernel.h"
+#include "blosclz_kernel.h"
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -55,8 +56,8 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
-            EncodeStream es(ea, lds.data(), w);
-            es.run();
+            if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(ea, lds.data(), w); es.run(); }
+            else { EncodeStream<CODEC_LZ4> es(ea, lds.data(), w); es.run(); }
         }
     }
     AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks, nullptr, nullptr};
@@ -127,6 +128,29 @@ int emu_lz4_decode(const uint8_t* src, int csize, uint8_t* dst, int n)
     const int park = rs - round16(csize);
     memcpy(lds.data() + park, src, (size_t)csize);
     const int rc = lz4_decode_wave(lds.data(), 0, n, park, csize, rs + 32);
+    memcpy(dst, lds.data(), (size_t)n);
+    return rc;
+}
+
+// single-stream entry points for the BloscLZ wave codec
+int emu_blosclz_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int clevel, int* need)
+{
+    const int lds_bytes = blz_encode_lds_bytes(n);
+    std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK, 0xCD);
+    memcpy(lds.data(), src, (size_t)n);
+    int nd = 0;
+    const int r = blosclz_encode_body(lds.data(), lds.data() + round16(n) + 16, n, dst, cap, clevel, nd);
+    if (need) *need = nd;
+    return r;
+}
+
+int emu_blosclz_decode(const uint8_t* src, int csize, uint8_t* dst, int n)
+{
+    const int rs = blz_region_stride(n);
+    std::vector<uint8_t> lds((size_t)rs + 32 + EMU_LDS_SLACK, 0xCD);
+    const int park = rs - round16(csize);
+    memcpy(lds.data() + park, src, (size_t)csize);
+    const int rc = blosclz_decode_wave(lds.data(), 0, n, park, csize, rs + 32);
     memcpy(dst, lds.data(), (size_t)n);
     return rc;
 }

@@ -5,6 +5,7 @@
 // only tests load; the product links libcimg_hip.so and has no such path.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/cimg_hip.h"
@@ -17,7 +18,8 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
                          uint8_t* raw, const int64_t* raw_off, int32_t* status);
 }
 
-struct cimg_engine { std::string err; std::vector<uint8_t> stage; std::vector<int64_t> off; std::vector<int32_t> len; };
+struct cimg_engine { std::string err; std::vector<uint8_t> stage; std::vector<int64_t> off; std::vector<int32_t> len; std::recursive_mutex mu; };
+#define LOCK_ENGINE(e) std::lock_guard<std::recursive_mutex> lock_((e)->mu)
 static std::string g_err;
 
 extern "C" {
@@ -31,12 +33,15 @@ int cimg_engine_create(int, cimg_engine** out) { *out = new cimg_engine(); retur
 void cimg_engine_destroy(cimg_engine* e) { delete e; }
 const char* cimg_last_error(const cimg_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
 int cimg_engine_synchronize(cimg_engine*) { return 0; }
+void cimg_engine_lock(cimg_engine* e) { e->mu.lock(); }
+void cimg_engine_unlock(cimg_engine* e) { e->mu.unlock(); }
 void* cimg_host_malloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
 void cimg_host_free(void* p) { free(p); }
 
 int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
                                    const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
 {
+    LOCK_ENGINE(e);
     e->off.clear();
     if (n <= 0) return 0;
     EmuCParams ep;
@@ -56,6 +61,7 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
 
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t n, void* h_comp, const int64_t* comp_off)
 {
+    LOCK_ENGINE(e);
     if (n <= 0) return 0;
     if ((size_t)n != e->off.size()) { e->err = "no compressed batch is waiting to be fetched"; return -12; }
     for (int i = 0; i < n; i++) if (e->len[(size_t)i] > 0) memcpy((uint8_t*)h_comp + comp_off[i], e->stage.data() + e->off[(size_t)i], (size_t)e->len[(size_t)i]);
@@ -66,6 +72,7 @@ int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t n, void* h_comp, cons
 int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
                              const int32_t* nbytes, void* h_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
 {
+    LOCK_ENGINE(e);
     if (n <= 0) return 0;
     const int rc = cimg_compress_batch_host_begin(e, p, n, h_raw, raw_off, nbytes, destsize, cbytes);
     if (rc) return rc;
@@ -75,7 +82,9 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, c
 int cimg_decompress_batch_host(cimg_engine* e, int32_t n, const void* h_comp, const int64_t* comp_off, void* h_raw,
                                const int64_t* raw_off, const int32_t* cap, int32_t* status)
 {
+    LOCK_ENGINE(e);
     if (n <= 0) return 0;
+    e->off.clear();                                          // as the engine: the staging area is reused, a pending _fetch is void
     std::vector<int32_t> nb((size_t)n), bs((size_t)n), st((size_t)n, 0);
     for (int i = 0; i < n; i++) {
         const uint8_t* c = (const uint8_t*)h_comp + comp_off[i];

@@ -24,13 +24,13 @@ def eng():
     e.close()
 
 
-def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9, filters=(0, 0, 0, 0, 0, 1), splitmode=3):
+def _roundtrip(eng, dtype, arr, chunk, blocksize=32768, destsize=None, clevel=9, filters=(0, 0, 0, 0, 0, 1), splitmode=3, compcode=1):
     it = np.dtype(dtype).itemsize
     raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
     sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
     dsz = [chunk + 32 if destsize is None else destsize] * len(sizes)
-    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters, splitmode=splitmode), raw, sizes, dsz)
-    po = O.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters, splitmode=splitmode)
+    chunks = eng.compress_host(hip.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters, splitmode=splitmode, compcode=compcode), raw, sizes, dsz)
+    po = O.cparams(it, clevel=clevel, blocksize=blocksize, filters=filters, splitmode=splitmode, compcode=compcode)
     off = 0
     for i, s in enumerate(sizes):
         r, want = O.compress(po, raw[off:off + s], destsize=dsz[i])
@@ -119,8 +119,8 @@ def test_empty_batch_and_unsupported_requests_fail_loudly(eng):
     with pytest.raises(hip.CodecError) as ei:
         eng.compress_host(hip.cparams(2, compcode=hip.ZSTD), raw, [raw.nbytes], [raw.nbytes + 32])
     assert ei.value.code == -7
-    with pytest.raises(hip.CodecError):
-        eng.compress_host(hip.cparams(2, compcode=hip.BLOSCLZ), raw, [raw.nbytes], [raw.nbytes + 32])
+    with pytest.raises(hip.CodecError):                                       # lz4hc: decode only
+        eng.compress_host(hip.cparams(2, compcode=hip.LZ4HC), raw, [raw.nbytes], [raw.nbytes + 32])
     with pytest.raises(hip.CodecError):                                       # a second filter in the pipeline
         eng.compress_host(hip.cparams(2, filters=(0, 0, 0, 0, hip.SHUFFLE, hip.BITSHUFFLE)), raw, [raw.nbytes], [raw.nbytes + 32])
 
@@ -446,3 +446,140 @@ def test_randomized_geometries_against_the_oracle(eng):
                     assert outs[k].tobytes() == raw[off:off + s].tobytes(), (it, i)
                     k += 1
                 off += s
+
+
+# ---- BloscLZ (enums::codec::blosclz) and lz4hc chunks ---------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float16, np.float32])
+@pytest.mark.parametrize("family", ["tiled", "zero", "random", "natural"])
+def test_blosclz_bytes_and_pixels_equal_oracle(eng, dtype, family):
+    arr = getattr(synth, family + "_channel")(dtype, 1024, 200)
+    it = np.dtype(dtype).itemsize
+    for clevel in (9, 5, 2):
+        _roundtrip(eng, dtype, arr, 4 * 1024 * 1024 // (1024 * it) * 1024 * it, clevel=clevel, compcode=hip.BLOSCLZ)
+    _roundtrip(eng, dtype, arr[:100], 40000 // it * it, compcode=hip.BLOSCLZ)                  # leftover blocks, short last chunk
+    _roundtrip(eng, dtype, arr[:64], 65536, blocksize=4096, compcode=hip.BLOSCLZ, clevel=7)
+
+
+def test_blosclz_golden_vectors_through_the_gpu_encoder(eng, golden_dir):
+    """typesize 1, no filter, block = whole chunk: the chunk's single stream IS the blosclz_compress call, and the
+    vectors are what c-blosc 1.21's BloscLZ 2.3.0 emitted (tests/golden/make_blosclz_golden.py)."""
+    kat = np.load(os.path.join(golden_dir, "blosclz_kat.npz"))
+    by_level = {}
+    for name in kat["cases"]:
+        fam, n, clevel = str(name).rsplit("|", 2)
+        by_level.setdefault(int(clevel), []).append((str(name), fam, int(n)))
+    checked = 0
+    for clevel, cases in sorted(by_level.items()):
+        raw = np.concatenate([kat[f"in|{fam}|{n}"] for _, fam, n in cases])
+        sizes = [n for _, _, n in cases]
+        p = hip.cparams(1, clevel=clevel, blocksize=65535, filters=(0, 0, 0, 0, 0, 0), splitmode=2, compcode=hip.BLOSCLZ)
+        chunks = eng.compress_host(p, raw, sizes, [s + 4096 for s in sizes])
+        for (name, fam, n), c in zip(cases, chunks):
+            src = kat[f"in|{fam}|{n}"]
+            if (src == src[0]).all():
+                continue                                            # run token, the codec is not called
+            want = kat["out|" + name].tobytes()
+            (cs,) = struct.unpack_from("<i", c, 32 + 4)
+            if want:
+                assert cs == len(want) and c[40:40 + cs] == want, name
+            else:
+                assert cs == n and c[40:40 + n] == src.tobytes(), name
+            checked += 1
+        outs, status = eng.decompress_host(chunks)
+        assert not status.any() and b"".join(o.tobytes() for o in outs) == raw.tobytes()
+    assert checked > 200
+
+
+def test_config1_as_named_blosclz_u8(eng):
+    """BASELINE configs[0] as named: one 1024^2 uint8 channel, blosclz level 9 -> a single 1 MiB remainder chunk in the
+    nominal 4 MiB + 32 buffer (schunk.h:73)."""
+    rng = np.random.default_rng(11)
+    for arr in (synth.tiled_channel(np.uint8, 1024, 1024), synth.natural_channel(np.uint8, 1024, 1024),
+                rng.integers(0, 256, 1024 * 1024, dtype=np.uint8)):
+        (c,) = _roundtrip(eng, np.uint8, arr, 1024 * 1024, destsize=4 * 1024 * 1024 + 32, compcode=hip.BLOSCLZ)
+        assert struct.unpack_from("<i", c, 4)[0] == 1024 * 1024 and (c[2] >> 5) == 0
+    assert len(c) > 1024 * 1024 + 32 and not (c[2] & 0x02)        # random bytes: framed, not memcpyed
+
+
+@pytest.mark.parametrize("filt", ["shuffle", "bitshuffle"])
+def test_config3_as_named_blosclz_full_size_random_access(eng, filt):
+    """BASELINE configs[2] as named: an 8192^2 uint16 channel, blosclz level 9 (+ bitshuffle; the reference's own filter
+    is the byte shuffle: both run), 32 chunks of 4 MiB, visited in a seeded random permutation: get_chunk, +1, set_chunk."""
+    filters = (0, 0, 0, 0, 0, hip.BITSHUFFLE if filt == "bitshuffle" else hip.SHUFFLE)
+    rng = np.random.default_rng(99)
+    chan = synth.tiled_channel(np.uint16, 8192, 8192, c=1)
+    host = chan.view(np.uint8).ravel()
+    n, chunk = host.size, 4 * 1024 * 1024
+    nchunks, stride = n // chunk, chunk + 64
+    d_raw, d_comp, d_one = eng.alloc(n), eng.alloc(nchunks * stride), eng.alloc(chunk)
+    d_raw.upload(host)
+    raw_off, comp_off = np.arange(nchunks) * chunk, np.arange(nchunks) * stride
+    p = hip.cparams(2, compcode=hip.BLOSCLZ, filters=filters)
+    cbytes = eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+    assert (cbytes > 32).all() and (cbytes < chunk).all()
+    po = O.cparams(2, compcode=O.BLOSCLZ, filters=filters)
+    order = rng.permutation(nchunks)
+    for i in order[:12]:
+        eng.decompress_device(d_comp.ptr + int(comp_off[i]), [0], [chunk], [32768], d_one.ptr, [0])       # get_chunk
+        px = d_one.download().view(np.uint16) + np.uint16(1)
+        d_one.upload(px)
+        cbytes[i] = eng.compress_device(p, d_one.ptr, [0], [chunk], d_comp.ptr + int(comp_off[i]), [0], [chunk + 32])[0]   # set_chunk
+    comp = d_comp.download()
+    want_px = chan.ravel().copy()
+    for i in order[:12]:
+        want_px[i * chunk // 2:(i + 1) * chunk // 2] += np.uint16(1)
+    for i in list(order[:3]) + list(order[-3:]):                   # bytes against the oracle on a sample ...
+        r, want = O.compress(po, want_px.view(np.uint8)[i * chunk:(i + 1) * chunk], destsize=chunk + 32)
+        assert cbytes[i] == r and comp[comp_off[i]:comp_off[i] + r].tobytes() == want, i
+    eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_raw.ptr, raw_off)
+    assert d_raw.download().tobytes() == want_px.tobytes()         # ... pixels everywhere
+    for buf in (d_raw, d_comp, d_one):
+        buf.free()
+
+
+def test_blosclz_edge_geometries_and_destsize_rule(eng):
+    rng = np.random.default_rng(4)
+    _roundtrip(eng, np.uint8, np.arange(50, dtype=np.uint8), 4194304, compcode=hip.BLOSCLZ)     # test_channel.cpp:74-87 (one tiny chunk)
+    _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 300, 41), 5000, blocksize=256, compcode=hip.BLOSCLZ)
+    _roundtrip(eng, np.uint64, (rng.integers(0, 40, 6000, dtype=np.uint64) * 0x0101010101).astype(np.uint64), 16384, blocksize=4096, compcode=hip.BLOSCLZ)
+    _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 512, 256), 262144, blocksize=65534, compcode=hip.BLOSCLZ)
+    noisy = rng.integers(0, 65536, 20000, dtype=np.uint16)
+    noisy[3000:9000] = 7
+    noisy[9000:15000] = (np.arange(6000) // 50).astype(np.uint16)
+    for destsize in (40000 + 32, 39000, 36000, 30000, 20100, 200):               # blosc2's running-destsize rule
+        _roundtrip(eng, np.uint16, noisy, 40000, blocksize=4096, destsize=destsize, compcode=hip.BLOSCLZ)
+    for splitmode, filters in ((2, (0, 0, 0, 0, 0, 1)), (1, (0, 0, 0, 0, 0, 0)), (4, (0, 0, 0, 0, 0, 1))):
+        _roundtrip(eng, np.uint16, synth.natural_channel(np.uint16, 2048, 64), 131072, splitmode=splitmode, filters=filters, compcode=hip.BLOSCLZ)
+
+
+def test_damaged_blosclz_chunks_are_reported_not_crashed(eng):
+    a = synth.natural_channel(np.uint16, 1024, 64)
+    (good,) = eng.compress_host(hip.cparams(2, compcode=hip.BLOSCLZ), a, [a.nbytes], [a.nbytes + 32])
+    rng = np.random.default_rng(8)
+    agree = 0
+    for _ in range(60):
+        bad = bytearray(good)
+        k = int(rng.integers(32 + 16, len(bad)))
+        bad[k] ^= 1 << int(rng.integers(0, 8))
+        r, pix = O.decompress(bytes(bad), a.nbytes)
+        try:
+            outs, status = eng.decompress_host([bytes(bad)])
+            ok = not status.any()
+        except hip.CodecError:
+            ok = False
+        assert ok == (r == a.nbytes)
+        if ok:
+            assert outs[0].tobytes() == pix.tobytes()
+        agree += 1
+    assert agree == 60
+
+
+def test_lz4hc_chunks_decode_on_the_gpu(eng, golden_dir):
+    """enums::codec::lz4hc chunks (coded by liblz4's LZ4_compress_HC, tests/golden/make_lz4hc_golden.py) are codec
+    format 1: they decode through the ordinary kernels; compressing with lz4hc is refused (test above)."""
+    kat = np.load(os.path.join(golden_dir, "lz4hc_kat.npz"))
+    chunks = [kat["chunk|" + str(n)].tobytes() for n in kat["cases"]]
+    outs, status = eng.decompress_host(chunks)
+    assert not status.any()
+    for n, o in zip(kat["cases"], outs):
+        assert o.tobytes() == kat["in|" + str(n)].tobytes(), n

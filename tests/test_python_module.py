@@ -71,13 +71,13 @@ def test_channel_behaviour(backend, dtype):
     rng = np.random.default_rng(0)
     for width, height in shapes(backend):
         it = np.dtype(dtype).itemsize
-        # initialization + row-sized chunks (test_channel.py:42-69; lz4 here: blosclz is not built on the GPU path)
+        # initialization + row-sized chunks, blosclz level 2 as in the reference (test_channel.py:42-69)
         arr = (rng.integers(0, 50, (height, width)) * (np.arange(width) // 7 % 5)).astype(dtype)
-        ch = ci.Channel(arr, width, height, chunk_size=width * it, compression_codec=ci.Codec.lz4, compression_level=2)
+        ch = ci.Channel(arr, width, height, chunk_size=width * it, compression_codec=ci.Codec.blosclz, compression_level=2)
         assert ch.num_chunks() == height and ch.chunk_size() == width * it
         assert (ch.height, ch.width, ch.shape) == (height, width, (height, width))
         assert ch.uncompressed_size() == width * height
-        assert ch.compression() == ci.Codec.lz4 and ch.compression_level() == 2
+        assert ch.compression() == ci.Codec.blosclz and ch.compression_level() == 2
         assert ch.dtype == np.dtype(dtype)
         out = ch.get_decompressed()
         assert out.dtype == np.dtype(dtype) and np.array_equal(out, arr)
