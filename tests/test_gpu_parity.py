@@ -516,7 +516,9 @@ def test_config3_as_named_blosclz_full_size_random_access(eng, filt):
     raw_off, comp_off = np.arange(nchunks) * chunk, np.arange(nchunks) * stride
     p = hip.cparams(2, compcode=hip.BLOSCLZ, filters=filters)
     cbytes = eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
-    assert (cbytes > 32).all() and (cbytes < chunk).all()
+    # (bit rows: BloscLZ 2.3.0 probes the first eighth of a stream -- the noise bits -- gives up, and the chunks come out
+    # memcpyed; the byte-shuffled planes compress)
+    assert (cbytes > 32).all() and ((cbytes < chunk).all() or filt == "bitshuffle")
     po = O.cparams(2, compcode=O.BLOSCLZ, filters=filters)
     order = rng.permutation(nchunks)
     for i in order[:12]:
