@@ -39,74 +39,161 @@ CHUNK = 4 * 1024 * 1024
 BLOCK = 32768
 
 
-def cpu_baseline(raw_channels, budget_s=10.0, threads=16):
-    """Oracle compress+decompress of the same chunks on this GPU's share of the host cores (bounded sample)."""
-    from concurrent.futures import ThreadPoolExecutor
+def _oracle_batch_lib():
+    import ctypes as C
     import _oracle as O
+    L = O.lib()
+    L.orc_bench_compress.argtypes = [C.POINTER(O.CParams), C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_int64, C.c_int32,
+                                     C.c_void_p, C.c_int, C.c_int]
+    L.orc_bench_compress.restype = C.c_int64
+    L.orc_bench_decompress.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
+    L.orc_bench_decompress.restype = C.c_int64
+    return L, O
+
+
+def cpu_baseline(host, budget_s=10.0, policy="all_cores"):
+    """The oracle (C, -O3, OpenMP inside the library: no Python in the timed region) over the same chunks.
+
+    policy "all_cores": an OpenMP loop over chunks on this GPU's share of the host cores (16 of an 8-GPU host).
+    policy "reference": the reference's own call structure -- chunks one after the other (schunk.h:85-94), compression
+    with hardware_concurrency() / 2 threads over the blocks of a chunk (channel.h:127), decompression on ONE thread
+    (wrapper.h:406)."""
+    L, O = _oracle_batch_lib()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(avail, threads)                              # 16 = one GPU's share of an 8-GPU host's cores
-    O.lib()
+    share = min(avail, 16)
+    if policy == "all_cores":
+        enc_chunks, enc_blocks, dec_chunks, cores = share, 1, share, share
+    else:
+        enc_chunks, enc_blocks, dec_chunks, cores = 1, max(1, share // 2), 1, max(1, share // 2)
     p = O.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK)
-    pieces = []
-    for ch in raw_channels:                                  # all 4 channels = 32 chunks x 4 MiB
-        raw = ch.view(np.uint8).ravel()
-        pieces += [raw[o:o + CHUNK] for o in range(0, raw.size, CHUNK)]
-    nbytes = sum(x.size for x in pieces)
+    nchunks = host.size // CHUNK
+    stride = CHUNK + 64
+    comp = np.zeros(nchunks * stride, np.uint8)
+    out = np.zeros(host.size, np.uint8)
+    cb = np.zeros(nchunks, np.int32)
+    vp = lambda a: a.ctypes.data_as(__import__("ctypes").c_void_p)
+    import ctypes as C
 
-    def one(piece):
-        r, c = O.compress(p, piece, destsize=CHUNK + 32)
-        rr, out = O.decompress(c, piece.size)
-        return r, rr
-
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(one, pieces))                           # warm
+    def one_pass():
         t0 = time.perf_counter()
+        r = L.orc_bench_compress(C.byref(p), vp(host), nchunks, CHUNK, vp(comp), stride, CHUNK + 32, vp(cb), enc_chunks, enc_blocks)
+        t1 = time.perf_counter()
+        d = L.orc_bench_decompress(vp(comp), nchunks, stride, vp(cb), vp(out), CHUNK, dec_chunks)
+        t2 = time.perf_counter()
+        assert r > 0 and d == host.size
+        return t1 - t0, t2 - t1
+
+    one_pass()                                               # warm
+    assert out.tobytes() == host.tobytes()
+    te = td = 0.0
+    reps = 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < budget_s:
+        a, b = one_pass()
+        te += a; td += b; reps += 1
+    n = host.size
+    return {"value": round(reps * 2 * n / (te + td) / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "compress_GBps": round(reps * n / te / 1e9, 3), "decompress_GBps": round(reps * n / td / 1e9, 3),
+            "policy": policy,
+            "sample": f"oracle (oracle/ CPU restatement at -O3, not c-blosc2): the same {nchunks} chunks x 4 MiB, {reps} passes in "
+                      f"{te + td:.1f} s; compress: {enc_chunks} thread(s) over chunks x {enc_blocks} over blocks, decompress: "
+                      f"{dec_chunks} thread(s) over chunks ({avail} hardware threads visible)"}
+
+
+def cblosc2_baseline(host, budget_s=8.0):
+    """The genuine CPU codec, if a c-blosc2 shared library is installed on this box (it is not in the image this was
+    written on): called exactly as the reference does -- one blosc2_compress_ctx per 4 MiB chunk, chunks serial,
+    nthreads = hw / 2 for compression and 1 for decompression.  Returns None when the library is absent."""
+    import ctypes as C
+    import ctypes.util
+    name = os.environ.get("CIMG_BLOSC2_LIB") or ctypes.util.find_library("blosc2")
+    if not name:
+        return None
+    try:
+        B = C.CDLL(name)
+        B.blosc2_init()
+        B.blosc2_compress.restype = C.c_int          # (clevel, doshuffle, typesize, src, srcsize, dest, destsize)
+        B.blosc2_compress.argtypes = [C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        B.blosc2_decompress.restype = C.c_int
+        B.blosc2_decompress.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        B.blosc1_set_compressor.argtypes = [C.c_char_p]
+        B.blosc2_set_nthreads.argtypes = [C.c_int16]
+        B.blosc1_set_blocksize.argtypes = [C.c_size_t]
+        B.blosc1_set_compressor(b"lz4")
+        B.blosc1_set_blocksize(BLOCK)
+        avail = len(os.sched_getaffinity(0))
+        enc_threads = max(1, min(avail, 16) // 2)
+        nchunks = host.size // CHUNK
+        comp = np.zeros(nchunks * (CHUNK + 64), np.uint8)
+        out = np.zeros(host.size, np.uint8)
+        cb = [0] * nchunks
+        te = td = 0.0
         reps = 0
-        while True:
-            list(ex.map(one, pieces))
-            reps += 1
-            if time.perf_counter() - t0 > budget_s:
-                break
-        dt = time.perf_counter() - t0
-    gbps = reps * 2 * nbytes / dt / 1e9
-    return {"value": round(gbps, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (oracle/ CPU restatement, not c-blosc2): the same {len(pieces)} chunks x 4 MiB, "
-                      f"compress+decompress per chunk, {reps} passes over a {cores}-thread pool in {dt:.1f} s "
-                      f"({avail} hardware threads visible)"}
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < budget_s:
+            B.blosc2_set_nthreads(enc_threads)
+            t0 = time.perf_counter()
+            for i in range(nchunks):
+                cb[i] = B.blosc2_compress(9, 1, 2, host.ctypes.data + i * CHUNK, CHUNK, comp.ctypes.data + i * (CHUNK + 64), CHUNK + 32)
+            t1 = time.perf_counter()
+            B.blosc2_set_nthreads(1)
+            for i in range(nchunks):
+                B.blosc2_decompress(comp.ctypes.data + i * (CHUNK + 64), cb[i], out.ctypes.data + i * CHUNK, CHUNK)
+            t2 = time.perf_counter()
+            te += t1 - t0; td += t2 - t1; reps += 1
+        if out.tobytes() != host.tobytes():
+            return None
+        n = host.size
+        return {"value": round(reps * 2 * n / (te + td) / 1e9, 3), "unit": "GB/s", "cores": enc_threads, "kind": "c-blosc2",
+                "compress_GBps": round(reps * n / te / 1e9, 3), "decompress_GBps": round(reps * n / td / 1e9, 3),
+                "library": name, "sample": f"{nchunks} chunks x 4 MiB, {reps} passes, reference call structure"}
+    except (OSError, AttributeError):
+        return None
 
 
-# HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KiB), which cannot be collected
-# from inside this process: the committed per-launch averages of the same workload are reported instead
-# (profiles/tools/collect.sh makes them).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the
-# bytes of 16-B-per-lane streaming reads -- the decoder stages compressed bytes that way (x2); the encoder's strided
-# byte-plane gather is calibrated against its known read volume (every raw byte exactly once: factor 1).
+# HBM traffic per launch comes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, KiB; separate runs, they cannot be
+# collected from inside this process).  profiles/tools/collect.sh stores the per-launch averages TOGETHER WITH a hash of
+# the kernel sources they were collected on; the figure is reported only when that hash equals the hash of the sources
+# this run was built from (else null), or when --pmc-json names a file explicitly.
+# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts HALF the bytes of 16-B-per-lane streaming reads, which
+# is how every kernel here reads its bulk input, so FETCH_SIZE is doubled; WRITE_SIZE is exact for 16-B stores.
 TIMING_PERIOD = 4
 FILTER_TEXT = {"shuffle": "byte shuffle", "bitshuffle": "bitshuffle (one unsplit stream per block)", "none": "no filter"}
-PMC_FILES = ("final_pmc_per_launch.json", "mid_pmc_per_launch.json")
-FETCH_FACTOR = {"cimg_encode_streams": 1.0, "cimg_decode_blocks": 2.0, "cimg_decode_lean": 2.0}
+FETCH_FACTOR = 2.0
 # the decode entry of the engine timers covers two launches (lean kernel + general kernel behind it)
 PMC_KERNELS = {"cimg_decode_blocks": ("cimg_decode_lean", "cimg_decode_blocks")}
 
 
-def pmc_traffic(kernel):
-    here = os.path.dirname(os.path.abspath(__file__))
-    for name in PMC_FILES:
-        path = os.path.join(here, "profiles", "r01", name)
-        if not os.path.exists(path):
-            continue
-        try:
-            with open(path) as f:
-                table = json.load(f)
-            total, seen = 0.0, False
-            for k in PMC_KERNELS.get(kernel, (kernel,)):
-                c = table.get(k)
-                if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    total += (c["FETCH_SIZE"] * FETCH_FACTOR.get(k, 1.0) + c["WRITE_SIZE"]) * 1024
-                    seen = True
-            if seen:
-                return int(total), "profiles/r01/" + name
-        except (OSError, ValueError):
-            pass
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "compressed-image_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, explicit=None):
+    path = explicit or os.path.join(ROOT, "profiles", "r02", "pmc_per_launch.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        if not explicit and table.get("_source_hash") != kernel_source_hash():
+            return None, f"{os.path.relpath(path, ROOT)} is from other kernel sources ({table.get('_source_hash')}): not reported"
+        total, seen = 0.0, False
+        for k in PMC_KERNELS.get(kernel, (kernel,)):
+            c = table.get(k)
+            if c and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                total += (c["FETCH_SIZE"] * FETCH_FACTOR + c["WRITE_SIZE"]) * 1024
+                seen = True
+        if seen:
+            return int(total), f"{os.path.relpath(path, ROOT)} (sources {table.get('_source_hash')}, FETCH_SIZE x 2 per the gfx950 rule)"
+    except (OSError, ValueError):
+        pass
     return None, None
 
 
@@ -117,6 +204,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--family", default="tiled", choices=["tiled", "natural", "random", "zero"])
+    ap.add_argument("--pmc-json", default=None, help="per-launch PMC averages to take roofline.traffic from (profiles/tools/collect.sh)")
     ap.add_argument("--filter", default="shuffle", choices=["shuffle", "bitshuffle", "none"],
                     help="not part of the headline: the reference only uses byte shuffle")
     args = ap.parse_args()
@@ -231,8 +319,9 @@ def main():
         dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = algo[dom] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         dec_avg_s = ktimes[hip.K_DECODE][0] / max(ktimes[hip.K_DECODE][1], 1) * 1e-3
-        traffic, traffic_src = pmc_traffic(hip.KERNELS[dom]) if (args.family == "tiled" and args.filter == "shuffle") else (None, None)
-        dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE]) if (args.family == "tiled" and args.filter == "shuffle") else (None, None)
+        headline = args.family == "tiled" and args.filter == "shuffle"
+        traffic, traffic_src = pmc_traffic(hip.KERNELS[dom], args.pmc_json) if headline else (None, None)
+        dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE], args.pmc_json) if headline else (None, None)
         out = {
             "metric": "compress+decompress GB/s (uncompressed side)",
             "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3),
@@ -244,7 +333,7 @@ def main():
             "config": {"workload": f"{CHANNELS}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + {FILTER_TEXT[args.filter]}, "
                                    f"32 KiB blocks, 4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks, {2 * N // BLOCK} streams), "
                                    f"device-resident, family={args.family}",
-                       "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(C),
+                       "element_dtype": "float16", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(C),
                        "compression_ratio": round(world * N / total_c, 4) if total_c else None,
                        "roundtrip_GBps": round(world * args.steps * N / elapsed / 1e9, 3),
                        "parallelism": f"chunks sharded by rank x{world}, no data-path collective"},
@@ -260,9 +349,12 @@ def main():
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
         }
         if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle":
-            out["cpu_baseline"] = cpu_baseline(chans)
-            # the same port with one thread per chunk of the workload (all the chunk-level parallelism there is)
-            out["cpu_baseline_one_thread_per_chunk"] = cpu_baseline(chans, budget_s=8.0, threads=nchunks)
+            out["cpu_baseline"] = cpu_baseline(host, budget_s=10.0, policy="all_cores")
+            # the reference's own call structure (serial chunks, hw/2 threads inside a chunk for encode, 1 thread decode)
+            out["cpu_baseline_reference_policy"] = cpu_baseline(host, budget_s=8.0, policy="reference")
+            real = cblosc2_baseline(host)                     # only where a c-blosc2 library is installed
+            if real is not None:
+                out["cpu_baseline_cblosc2"] = real
         print(json.dumps(out))
     eng.close()
     if dist is not None:

@@ -22,7 +22,7 @@ EXPORTS = (
     # include/cimg_hip.h
     "cimg_cparams_init", "cimg_engine_create", "cimg_engine_destroy", "cimg_last_error",
     "cimg_engine_synchronize", "cimg_engine_lock", "cimg_engine_unlock", "cimg_engine_stream", "cimg_compress_batch_device",
-    "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host",
+    "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host", "cimg_decompress_batch_host_sized",
     "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
@@ -86,6 +86,7 @@ def load():
     L.cimg_decompress_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_compress_batch_host.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_decompress_batch_host.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.cimg_decompress_batch_host_sized.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_device_malloc.argtypes = [vp, C.c_size_t]
     L.cimg_device_malloc.restype = vp
     L.cimg_device_free.argtypes = [vp, vp]
@@ -247,8 +248,9 @@ class Engine:
         raw_off = _i64(np.concatenate([[0], np.cumsum(nb[:-1], dtype=np.int64)]))
         raw = np.zeros(max(int(nb.sum()), 1), np.uint8)
         status = np.zeros(nb.size, np.int32)
-        rc = load().cimg_decompress_batch_host(self.handle, nb.size, _ptr(comp), _ptr(comp_off), _ptr(raw), _ptr(raw_off),
-                                               _ptr(nb), _ptr(status))
+        held = _i32(sizes)
+        rc = load().cimg_decompress_batch_host_sized(self.handle, nb.size, _ptr(comp), _ptr(comp_off), _ptr(held), _ptr(raw), _ptr(raw_off),
+                                                     _ptr(nb), _ptr(status))
         if check:
             self._check(rc)
         return [raw[o:o + n] for o, n in zip(raw_off, nb)], status

@@ -660,6 +660,7 @@ struct DecodeBlock {
         neblock = bsize / ns;
         rs = fmt == 0 ? blz_region_stride(neblock) : region_stride(neblock);
         if (ns * rs + 16 > a.lds_bytes) { fail(ERR_FAILURE); return; }
+        if (cbytes < HEADER_LEN + 4 * d.nblocks) { fail(ERR_READ_BUFFER); return; }      // the bstarts table itself must be inside the chunk
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { fail(ERR_DATA); return; }
         mode = 0;

@@ -49,6 +49,7 @@ struct DecodeLean {
         if ((ts != 2 && ts != 4) || (bsize & 15) || bsize % ts) return;
         neblock = bsize / ts;
         if (region_stride(neblock) + 16 > a.lds_bytes) return;
+        if (cbytes < HEADER_LEN + 4 * d.nblocks) return;
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) return;
         int pos = bstart, coded = 0;

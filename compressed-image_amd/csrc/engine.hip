@@ -128,6 +128,9 @@ struct cimg_engine {
     int enc_wgs_codec = -1;
     bool stamps = false;
     bool trace = getenv("CIMG_TRACE") != nullptr;
+    // environment knobs are read ONCE, when the engine is created (diagnostics only; none changes results)
+    bool verbose = getenv("CIMG_VERBOSE") != nullptr;
+    int enc_wgs_limit = getenv("CIMG_ENC_WGS_PER_CU") ? atoi(getenv("CIMG_ENC_WGS_PER_CU")) : 0;
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
     int max_dyn_lds[4] = {0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
@@ -136,6 +139,7 @@ struct cimg_engine {
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
     void begin_batch(int which) { timing = timing_period > 0 && (batch_no[which]++ % timing_period) == 0; }
     std::vector<EventPair> pending[CIMG_K_COUNT];
+    std::vector<EventPair> pending_extra;   // late general decode launches: time counts towards CIMG_K_DECODE, launches do not
     std::vector<EventPair> free_events;
     double total_ms[CIMG_K_COUNT] = {0, 0, 0, 0};
     int64_t launches[CIMG_K_COUNT] = {0, 0, 0, 0};
@@ -220,6 +224,12 @@ struct cimg_engine {
             }
             pending[k].clear();
         }
+        for (EventPair& ev : pending_extra) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) total_ms[CIMG_K_DECODE] += ms;
+            free_events.push_back(ev);
+        }
+        pending_extra.clear();
     }
     template <class Args>
     int launch(int kid, void (*kernel)(Args), const Args& args, int grid, int block, int lds)
@@ -463,10 +473,10 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
             if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_kernel, 64, (size_t)lds_bytes), "occupancy query"))) return rc;
             e->enc_wgs_per_cu[split] = per_cu > 0 ? per_cu : 1;
             e->enc_wgs_lds[split] = lds_bytes;
-            if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] encode launch: %d bytes LDS -> %d workgroups per CU x %d CUs\n", lds_bytes, per_cu, e->num_cus);
+            if (e->verbose) fprintf(stderr, "[cimg] encode launch: %d bytes LDS -> %d workgroups per CU x %d CUs\n", lds_bytes, per_cu, e->num_cus);
         }
         int per_cu_use = e->enc_wgs_per_cu[split];
-        if (const char* o = getenv("CIMG_ENC_WGS_PER_CU")) per_cu_use = std::max(1, std::min(per_cu_use, atoi(o)));   // diagnostic: fewer resident workgroups
+        if (e->enc_wgs_limit > 0) per_cu_use = std::max(1, std::min(per_cu_use, e->enc_wgs_limit));   // diagnostic: fewer resident workgroups
         const int grid = std::min(items, per_cu_use * e->num_cus);
         if ((rc = e->launch(CIMG_K_ENCODE, enc_kernel, ea, grid, 64, lds_bytes))) return rc;
     }
@@ -539,7 +549,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     if (lean) {
         DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, nullptr,
                       plan.uniform_nblocks, done, e->done_gen, skipped_dev};
-        if (getenv("CIMG_VERBOSE") && !e->lean_batches) {
+        if (e->verbose && !e->lean_batches) {
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean, e->lean_threads, (size_t)plan.lds_lean);
             fprintf(stderr, "[cimg] lean decode launch: %d bytes LDS, %d threads -> %d workgroups per CU\n", plan.lds_lean, e->lean_threads, per_cu);
@@ -564,11 +574,16 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
         e->lean_batches++; e->lean_blocks_skipped += skipped; e->lean_blocks_total += plan.total_blocks;
         e->lean_last_skipped = skipped;
         if ((int64_t)skipped * 4 > plan.total_blocks) e->lean_hold = 16;
-        if (getenv("CIMG_VERBOSE")) fprintf(stderr, "[cimg] decode: lean kernel left %u of %d blocks to the general kernel%s\n", skipped, plan.total_blocks,
+        if (e->verbose) fprintf(stderr, "[cimg] decode: lean kernel left %u of %d blocks to the general kernel%s\n", skipped, plan.total_blocks,
                                             (!general_now && skipped) ? " (launched late)" : "");
         if (!general_now && skipped) {
+            // (timed batches: this launch gets its own event pair, added to the decode total without counting a second launch)
             if ((rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes))) return rc;
-            if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes))) return rc;
+            EventPair ev2{};
+            if (timed) { ev2 = e->get_events(); (void)hipEventRecord(ev2.a, e->stream); e->timing = false; }
+            rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);
+            if (timed) { e->timing = true; (void)hipEventRecord(ev2.b, e->stream); e->pending_extra.push_back(ev2); }
+            if (rc) return rc;
             if ((rc = cimg_engine_synchronize(e))) return rc;
         }
     }
@@ -653,6 +668,12 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchu
 int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_comp, const int64_t* comp_off,
                                void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity, int32_t* status)
 {
+    return cimg_decompress_batch_host_sized(e, nchunks, h_comp, comp_off, nullptr, h_raw, raw_off, raw_capacity, status);
+}
+
+int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void* h_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                     void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity, int32_t* status)
+{
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!h_comp || !h_raw || !comp_off || !raw_off || !raw_capacity) return e->fail(ERR_INVALID_PARAM, "null argument");
@@ -665,9 +686,11 @@ int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_co
     for (int i = 0; i < nchunks; i++) {
         const uint8_t* c = hc + comp_off[i];
         int32_t n, cbv, b;
+        if (comp_size && comp_size[i] < HEADER_LEN) return e->fail(ERR_READ_BUFFER, "chunk %d: %d bytes cannot hold a header", i, comp_size[i]);
         memcpy(&n, c + OFF_NBYTES, 4); memcpy(&b, c + OFF_BLOCKSIZE, 4); memcpy(&cbv, c + OFF_CBYTES, 4);
         if (c[0] > 5) return e->fail(ERR_VERSION_SUPPORT, "chunk %d: format version %d", i, c[0]);
         if (cbv < HEADER_LEN || b <= 0 || (n > 0 && b > n) || c[OFF_TYPESIZE] == 0) return e->fail(ERR_INVALID_HEADER, "chunk %d: invalid header", i);
+        if (comp_size && cbv > comp_size[i]) return e->fail(ERR_READ_BUFFER, "chunk %d: header says %d compressed bytes, the buffer holds %d", i, cbv, comp_size[i]);
         if (n > raw_capacity[i]) return e->fail(ERR_WRITE_BUFFER, "chunk %d: needs %d bytes, buffer has %d", i, n, raw_capacity[i]);
         nb[(size_t)i] = n; bs[(size_t)i] = b; cb[(size_t)i] = cbv;
         d_comp_off[(size_t)i] = comp_total; comp_total += ((int64_t)cbv + 63) & ~63ll;

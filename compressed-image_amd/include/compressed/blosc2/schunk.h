@@ -110,7 +110,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					for (const auto& c : m_Chunks)
 					{
 						if (!c.is_lazy())
-							work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels.data() + offset), c.num_elements * sizeof(T) });
+							work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels.data() + offset), c.num_elements * sizeof(T), c.bytes().size() });
 						offset += c.num_elements;
 					}
 					batch::decompress(work);
@@ -125,7 +125,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					for (const auto& c : m_Chunks)
 					{
 						if (c.is_lazy()) std::fill(pixels + offset, pixels + offset + c.num_elements, std::get<T>(c.value));
-						else work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels + offset), c.num_elements * sizeof(T) });
+						else work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels + offset), c.num_elements * sizeof(T), c.bytes().size() });
 						offset += c.num_elements;
 					}
 				}
@@ -139,7 +139,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 						validate_chunk_index(i);
 						const auto& c = m_Chunks[i];
 						if (c.is_lazy()) std::fill(pixels + offset, pixels + offset + c.num_elements, std::get<T>(c.value));
-						else work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels + offset), c.num_elements * sizeof(T) });
+						else work.push_back({ c.bytes().data(), reinterpret_cast<std::byte*>(pixels + offset), c.num_elements * sizeof(T), c.bytes().size() });
 						offset += c.num_elements;
 					}
 				}

@@ -264,7 +264,8 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 				return out;
 			}
 
-			struct target { const std::byte* chunk; std::byte* out; size_t capacity; };   // one chunk -> its pixels
+			// one chunk -> its pixels; chunk_bytes = what the chunk buffer really holds (0: unknown, trust the header)
+			struct target { const std::byte* chunk; std::byte* out; size_t capacity; size_t chunk_bytes = 0; };
 
 			inline void decompress(const std::vector<target>& items)
 			{
@@ -274,16 +275,20 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 				std::byte* rbase = items[0].out;
 				for (const auto& t : items) { if (t.chunk < cbase) cbase = t.chunk; if (t.out < rbase) rbase = t.out; }
 				std::vector<int64_t> comp_off(n), raw_off(n);
-				std::vector<int32_t> cap(n), status(n);
+				std::vector<int32_t> cap(n), status(n), held(n);
+				bool sized = true;
 				for (size_t i = 0; i < n; ++i)
 				{
+					sized = sized && items[i].chunk_bytes > 0 && items[i].chunk_bytes <= static_cast<size_t>(std::numeric_limits<int32_t>::max());
+					held[i] = static_cast<int32_t>(items[i].chunk_bytes);
 					if (items[i].capacity > static_cast<size_t>(std::numeric_limits<int32_t>::max()))
 						throw std::out_of_range(detail::text("Blosc2 chunk size may not exceed numeric limit of int32_t, got ", items[i].capacity, " which would exceed that"));
 					comp_off[i] = items[i].chunk - cbase;
 					raw_off[i] = items[i].out - rbase;
 					cap[i] = static_cast<int32_t>(items[i].capacity);
 				}
-				const int rc = cimg_decompress_batch_host(engine(), static_cast<int32_t>(n), cbase, comp_off.data(), rbase, raw_off.data(), cap.data(), status.data());
+				const int rc = cimg_decompress_batch_host_sized(engine(), static_cast<int32_t>(n), cbase, comp_off.data(), sized ? held.data() : nullptr,
+					rbase, raw_off.data(), cap.data(), status.data());
 				if (rc < 0)
 					throw std::runtime_error(detail::text("Error code ", rc, " while decompressing blosc2 chunk"));
 			}

@@ -83,11 +83,18 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
                                    const void* h_raw, const int64_t* raw_off, const int32_t* nbytes,
                                    const int32_t* destsize, int32_t* cbytes);
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp, const int64_t* comp_off);
-/* Sizes are read from the chunk headers in host memory. */
+/* Sizes are read from the chunk headers in host memory (the reference passes INT32_MAX as srcsize, wrapper.h:249,
+ * so the header is all there is). */
 int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks,
                                const void* h_comp, const int64_t* comp_off,
                                void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity,
                                int32_t* status);
+/* The same for callers that know how many bytes each chunk buffer really holds: a header that claims more
+ * (truncated or hostile chunk) is refused with BLOSC2_ERROR_READ_BUFFER before anything is read past the buffer. */
+int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks,
+                                     const void* h_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                     void* h_raw, const int64_t* raw_off, const int32_t* raw_capacity,
+                                     int32_t* status);
 
 /* ---- glue between the blosc2 shim and the batched calls ----------------------------------------------
  * The single-chunk blosc2_*_ctx calls run on one process-wide engine (device $CIMG_DEVICE, else the

@@ -130,6 +130,10 @@ static void write_header(const orc_cparams* p, const orc_geometry* g, int32_t nb
 
 static int all_equal(const uint8_t* s, int n)
 {
+    if (n >= 16) {                                  /* s[0..n-8) == s[8..n): the period-8 test, then the first 8 bytes */
+        if (memcmp(s, s + 8, (size_t)n - 8) != 0) return 0;
+        n = 8;
+    }
     for (int i = 1; i < n; i++) if (s[i] != s[0]) return 0;
     return 1;
 }

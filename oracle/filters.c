@@ -14,9 +14,17 @@ void orc_shuffle(int ts, int bsize, const uint8_t* src, uint8_t* dst)
 {
     if (ts <= 1) { memcpy(dst, src, (size_t)bsize); return; }
     const int ne = bsize / ts;
-    for (int j = 0; j < ts; j++)
-        for (int i = 0; i < ne; i++)
-            dst[(size_t)j * ne + i] = src[(size_t)i * ts + j];
+    if (ts == 2) {                                  /* written so that the compiler vectorises it */
+        uint8_t* restrict d0 = dst; uint8_t* restrict d1 = dst + ne;
+        for (int i = 0; i < ne; i++) { d0[i] = src[2 * i]; d1[i] = src[2 * i + 1]; }
+    } else if (ts == 4) {
+        uint8_t* restrict d0 = dst; uint8_t* restrict d1 = dst + ne; uint8_t* restrict d2 = dst + 2 * (size_t)ne; uint8_t* restrict d3 = dst + 3 * (size_t)ne;
+        for (int i = 0; i < ne; i++) { d0[i] = src[4 * i]; d1[i] = src[4 * i + 1]; d2[i] = src[4 * i + 2]; d3[i] = src[4 * i + 3]; }
+    } else {
+        for (int j = 0; j < ts; j++)
+            for (int i = 0; i < ne; i++)
+                dst[(size_t)j * ne + i] = src[(size_t)i * ts + j];
+    }
     const int done = ne * ts;
     memcpy(dst + done, src + done, (size_t)(bsize - done));
 }
@@ -25,9 +33,17 @@ void orc_unshuffle(int ts, int bsize, const uint8_t* src, uint8_t* dst)
 {
     if (ts <= 1) { memcpy(dst, src, (size_t)bsize); return; }
     const int ne = bsize / ts;
-    for (int i = 0; i < ne; i++)
-        for (int j = 0; j < ts; j++)
-            dst[(size_t)i * ts + j] = src[(size_t)j * ne + i];
+    if (ts == 2) {
+        const uint8_t* restrict s0 = src; const uint8_t* restrict s1 = src + ne;
+        for (int i = 0; i < ne; i++) { dst[2 * i] = s0[i]; dst[2 * i + 1] = s1[i]; }
+    } else if (ts == 4) {
+        const uint8_t* restrict s0 = src; const uint8_t* restrict s1 = src + ne; const uint8_t* restrict s2 = src + 2 * (size_t)ne; const uint8_t* restrict s3 = src + 3 * (size_t)ne;
+        for (int i = 0; i < ne; i++) { dst[4 * i] = s0[i]; dst[4 * i + 1] = s1[i]; dst[4 * i + 2] = s2[i]; dst[4 * i + 3] = s3[i]; }
+    } else {
+        for (int i = 0; i < ne; i++)
+            for (int j = 0; j < ts; j++)
+                dst[(size_t)i * ts + j] = src[(size_t)j * ne + i];
+    }
     const int done = ne * ts;
     memcpy(dst + done, src + done, (size_t)(bsize - done));
 }

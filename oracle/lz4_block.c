@@ -28,6 +28,12 @@ static inline int max_i(int a, int b) { return a > b ? a : b; }
 static int common_len(const uint8_t* a, const uint8_t* b, const uint8_t* a_end)
 {
     const uint8_t* s = a;
+    while (a + 8 <= a_end) {                       /* eight bytes at a time (same answer as the byte loop) */
+        uint64_t x, y;
+        memcpy(&x, a, 8); memcpy(&y, b, 8);
+        if (x != y) return (int)(a - s) + (__builtin_ctzll(x ^ y) >> 3);
+        a += 8; b += 8;
+    }
     while (a < a_end && *a == *b) { a++; b++; }
     return (int)(a - s);
 }
@@ -189,7 +195,9 @@ int orc_lz4_decompress_safe(const uint8_t* src, int csize, uint8_t* dst, int cap
         }
         mlen += MINMATCH;
         if (mlen > cap - op) return -1;
-        for (int k = 0; k < mlen; k++) dst[op + k] = dst[op + k - off];   /* overlap replicates */
+        if (off >= mlen) memcpy(dst + op, dst + op - off, (size_t)mlen);
+        else if (off == 1) memset(dst + op, dst[op - 1], (size_t)mlen);
+        else for (int k = 0; k < mlen; k++) dst[op + k] = dst[op + k - off];   /* overlap replicates */
         op += mlen;
     }
     return op;

@@ -79,11 +79,24 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, c
     return cimg_compress_batch_host_fetch(e, n, h_comp, comp_off);
 }
 
+int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t n, const void* h_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                     void* h_raw, const int64_t* raw_off, const int32_t* cap, int32_t* status);
 int cimg_decompress_batch_host(cimg_engine* e, int32_t n, const void* h_comp, const int64_t* comp_off, void* h_raw,
                                const int64_t* raw_off, const int32_t* cap, int32_t* status)
 {
+    return cimg_decompress_batch_host_sized(e, n, h_comp, comp_off, nullptr, h_raw, raw_off, cap, status);
+}
+int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t n, const void* h_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                     void* h_raw, const int64_t* raw_off, const int32_t* cap, int32_t* status)
+{
     LOCK_ENGINE(e);
     if (n <= 0) return 0;
+    if (comp_size)
+        for (int i = 0; i < n; i++) {
+            int32_t cb = 0;
+            if (comp_size[i] >= 16) memcpy(&cb, (const uint8_t*)h_comp + comp_off[i] + 12, 4);
+            if (comp_size[i] < 32 || cb > comp_size[i]) { e->err = "chunk buffer shorter than its header says"; return -5; }
+        }
     e->off.clear();                                          // as the engine: the staging area is reused, a pending _fetch is void
     std::vector<int32_t> nb((size_t)n), bs((size_t)n), st((size_t)n, 0);
     for (int i = 0; i < n; i++) {

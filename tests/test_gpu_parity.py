@@ -576,6 +576,18 @@ def test_damaged_blosclz_chunks_are_reported_not_crashed(eng):
     assert agree == 60
 
 
+def test_truncated_chunk_buffer_is_refused_before_it_is_read(eng):
+    """cimg_decompress_batch_host_sized: the header claims more compressed bytes than the buffer holds -> READ_BUFFER."""
+    a = synth.natural_channel(np.uint16, 512, 64)
+    (good,) = eng.compress_host(hip.cparams(2), a, [a.nbytes], [a.nbytes + 32])
+    for cut in (len(good) // 2, 40, 31, 8):
+        with pytest.raises(hip.CodecError) as ei:
+            eng.decompress_host([good[:cut]])
+        assert ei.value.code == -5
+    outs, status = eng.decompress_host([good])
+    assert outs[0].tobytes() == a.tobytes()
+
+
 def test_lz4hc_chunks_decode_on_the_gpu(eng, golden_dir):
     """enums::codec::lz4hc chunks (coded by liblz4's LZ4_compress_HC, tests/golden/make_lz4hc_golden.py) are codec
     format 1: they decode through the ordinary kernels; compressing with lz4hc is refused (test above)."""
