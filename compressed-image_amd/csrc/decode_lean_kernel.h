@@ -24,6 +24,10 @@ struct DecodeLean {
     int lz_pos = 0, lz_cs = 0, lz_plane = -1;
     const uint8_t* c = nullptr;
     uint8_t* out = nullptr;
+    // the stored plane of a two-plane block, requested from HBM BEFORE the serial LZ4 decode of the other plane and kept in
+    // registers until the un-shuffle (16 KiB = 16 x 16 bytes per lane): its latency hides behind the decode
+    LV<u128> pre[16];
+    int prefetched = 0;
 
     CIMG_DEV DecodeLean(const DecodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
 
@@ -76,10 +80,33 @@ struct DecodeLean {
         // which wave runs the serial LZ4 chain (the launch uses ONE wave per block: 9 blocks per CU and the hardware
         // spreads them over the SIMDs; with 4 waves per block 3 of them only wait and the chains clump: 137 vs 125 us)
         const int lzwave = (int)((((uint32_t)b * 2654435761u) >> 30) & (uint32_t)(nwaves - 1));   // nwaves is 1, 2 or 4
+        // one wave per block (the launch shape): that wave can carry the stored plane through the decode in registers
+        // (static indices only: a dynamically indexed member array would push the whole object, pre[] included, to scratch)
+        const bool raw0 = kind[0] == 1, raw1 = kind[1] == 1;
+        const int raw_at = raw0 ? at[0] : at[1];
+        const bool want_pre = nwaves == 1 && ts == 2 && neblock == 16384 && (raw0 != raw1);
         if (coded == 1 && wave == lzwave) {
             const int rs = region_stride(neblock);
             const int park = rs - round16(lz_cs);
-            wave_copy_g2l(c + lz_pos, lds, park, lz_cs);
+            debug_stamp(a.dbg, b, 1);                                             // header walk done
+            if (want_pre && lz_cs <= 4096) {
+                // coded bytes first, stored plane behind them: the wait for the coded bytes leaves the 16 plane loads in flight
+                const int units = lz_cs >> 4;
+                LV<u128> t[4];
+                CIMG_UNROLL
+                for (int k = 0; k < 4; k++) { FOR_LANES(l) { t[k][l] = ld128u(c + lz_pos + 16 * imin(64 * k + l, imax(units - 1, 0))); } }
+                LV<uint32_t> tailb;
+                FOR_LANES(l) { tailb[l] = c[lz_pos + imin((units << 4) + l, lz_cs - 1)]; }
+                CIMG_UNROLL
+                for (int k = 0; k < 16; k++) { FOR_LANES(l) { pre[k][l] = ld128u(c + raw_at + 1024 * k + 16 * l); } }
+                prefetched = 1;
+                CIMG_UNROLL
+                for (int k = 0; k < 4; k++) { FOR_LANES(l) { if (64 * k + l < units) st128a(lds + park + 16 * (64 * k + l), t[k][l]); } }
+                FOR_LANES(l) { if ((units << 4) + l < lz_cs) lds[park + (units << 4) + l] = (uint8_t)tailb[l]; }
+            } else {
+                wave_copy_g2l(c + lz_pos, lds, park, lz_cs);
+            }
+            debug_stamp(a.dbg, b, 2);                                             // coded bytes staged
             const int rc = lz4_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes);
             // the verdict travels to the other waves through the last LDS word of the allocation
             FOR_LANES_W(l) { *reinterpret_cast<int32_t*>(lds + a.lds_bytes - 4) = rc; }
@@ -106,6 +133,26 @@ struct DecodeLean {
             LV<int32_t> rc;
             FOR_LANES(l) { rc[l] = *reinterpret_cast<const int32_t*>(lds + a.lds_bytes - 4); }
             if (readlane(rc, 0) < 0) { leave(wave); return; }                 // damaged stream: the general kernel reports it
+        }
+        if (prefetched) {
+            // lane l, piece k: plane bytes [1024 k + 16 l, + 16) of both planes -> 32 contiguous pixels bytes
+            CIMG_UNROLL
+            for (int k = 0; k < 16; k++) {
+                FOR_LANES(l) {
+                    const int off = 1024 * k + 16 * l;
+                    const u128 x = ld128a(lds + off);
+                    const u128 lo = lz_plane == 0 ? x : pre[k][l], hi = lz_plane == 0 ? pre[k][l] : x;    // plane 0 = low bytes
+                    u128 o0, o1;
+                    o0.x = byte_perm(hi.x, lo.x, 0x05010400u); o0.y = byte_perm(hi.x, lo.x, 0x07030602u);
+                    o0.z = byte_perm(hi.y, lo.y, 0x05010400u); o0.w = byte_perm(hi.y, lo.y, 0x07030602u);
+                    o1.x = byte_perm(hi.z, lo.z, 0x05010400u); o1.y = byte_perm(hi.z, lo.z, 0x07030602u);
+                    o1.z = byte_perm(hi.w, lo.w, 0x05010400u); o1.w = byte_perm(hi.w, lo.w, 0x07030602u);
+                    st128u(out + 2 * off, o0);
+                    st128u(out + 2 * off + 16, o1);
+                }
+            }
+            if (wave == 0) { FOR_LANES_W(l) { a.done[b] = a.gen; } }
+            return;
         }
         const int units = bsize >> 4;
         const int tid0 = wave * 64, step = nwaves * 64;

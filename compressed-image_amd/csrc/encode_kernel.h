@@ -670,11 +670,11 @@ CIMG_DEV void wave_copy_l2g(const uint8_t* lds, int off, uint8_t* g, int nbytes)
 // two kernels (merged into one, the scalar state of both pushed the LZ4 kernel from 38 to 84 spilled SGPRs)
 template <int CODEC>
 struct EncodeStream {
-    const EncodeArgs& a;
+    kernarg_ptr<EncodeArgs> ap;     // wave.h: fields are loaded where they are used, not held in SGPRs across the codec loop
     uint8_t* lds;
     int w;
 
-    CIMG_DEV EncodeStream(const EncodeArgs& a_, uint8_t* lds_, int w_) : a(a_), lds(lds_), w(w_) {}
+    CIMG_DEV EncodeStream(kernarg_ptr<EncodeArgs> a_, uint8_t* lds_, int w_) : ap(a_), lds(lds_), w(w_) {}
 
     // phase A for a split block: keep byte plane s (or slice s when no shuffle) of the block
     CIMG_DEV void load_plane(const uint8_t* src, int bsize, int ts, int s, int neblock, bool shuf)
@@ -817,67 +817,84 @@ struct EncodeStream {
     // persistent workgroup: pull items until the queue is dry
     CIMG_DEV void run()
     {
-        const int items = encode_items(a.total_blocks, a.p.streams_per_block, a.want_split != 0);
+        int items;
+        uint32_t* queue;
+        {
+            const auto a = fresh(ap);
+            items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0);
+            queue = a->queue;
+        }
         // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
         for (int pops = 0; pops <= items; ++pops) {
             LV<uint32_t> got;
             FOR_LANES(l) { got[l] = 0; }
-            FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(a.queue); }
+            FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(queue); }
             const int item = uni((int)readlane(got, 0));
             if (item >= items) return;
             run_item(item);
         }
     }
 
-    CIMG_DEV void run_item(int item)
+    // block and stream of a work item (encode_items)
+    CIMG_DEV static void item_place(kernarg_ptr<EncodeArgs> a, int item, int& b, int& s)
     {
-        int b, s;
-        const int spb = a.p.streams_per_block;
-        if (a.want_split) {
-            b = item % a.total_blocks;
-            s = spb - 1 - item / a.total_blocks;
+        if (a->want_split) {
+            const int tb = a->total_blocks;
+            b = item % tb;
+            s = a->p.streams_per_block - 1 - item / tb;
         } else {
             b = item; s = 0;
         }
-        if (b >= a.total_blocks) return;
-        const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
-        const ChunkDesc d = uniform_desc(a.descs + chunk);
-        if (d.memcpyed) return;
-        const int j = b - d.blk0;
-        const int ts = a.p.typesize;
-        const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
-        const int bsize = leftover_blk ? d.leftover : d.blocksize;
-        const int ns = (d.split && !leftover_blk) ? ts : 1;
-        if ((ns > 1) != (a.want_split != 0) || s >= ns) return;
+    }
 
-        const int neblock = bsize / ns;
-        const uint8_t* src = a.raw + d.raw_off + (int64_t)j * d.blocksize;
-        const bool shuf = a.p.filter == FILTER_SHUFFLE && ts > 1;
+    CIMG_DEV void run_item(int item)
+    {
+        // ---- stage the stream: everything read from the arguments here is dead before the codec loop starts ----------
+        int neblock, accel_or_level;
+        uint8_t* out;
+        uint64_t* dbg;
+        {
+            const auto a = fresh(ap);
+            int b, s;
+            item_place(a, item, b, s);
+            if (b >= a->total_blocks) return;
+            const int chunk = find_chunk(a->descs, a->nchunks, b, a->uniform_nblocks);
+            const ChunkDesc d = uniform_desc(a->descs + chunk);
+            if (d.memcpyed) return;
+            const int j = b - d.blk0;
+            const int ts = a->p.typesize;
+            const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
+            const int bsize = leftover_blk ? d.leftover : d.blocksize;
+            const int ns = (d.split && !leftover_blk) ? ts : 1;
+            if ((ns > 1) != (a->want_split != 0) || s >= ns) return;
+            neblock = bsize / ns;
+            const uint8_t* src = a->raw + d.raw_off + (int64_t)j * d.blocksize;
+            const int filter = a->p.filter;
+            const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
+            out = a->scratch + (int64_t)b * a->p.slot_bytes + (int64_t)s * neblock;
+            accel_or_level = CODEC == CODEC_BLOSCLZ ? a->p.clevel : a->p.accel;
+            dbg = a->dbg;
 #if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-        const unsigned long long prof_load0_ = cimg_cycles();
+            const unsigned long long prof_load0_ = cimg_cycles();
 #endif
-        if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
-        else if (a.p.filter == FILTER_BITSHUFFLE) load_block_bitshuffle(src, bsize, ts);
-        else load_block(src, bsize, ts, shuf);
-
+            if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
+            else if (filter == FILTER_BITSHUFFLE) load_block_bitshuffle(src, bsize, ts);
+            else load_block(src, bsize, ts, shuf);
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+            if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 14] = cimg_cycles() - prof_load0_;
+#endif
+        }
         const uint8_t* in = lds;
-        uint8_t* out = a.scratch + (int64_t)b * a.p.slot_bytes + (int64_t)s * neblock;
         StreamRec r;
         r.kind = REC_RAW; r.value = 0; r.csize = neblock; r.need = 0;
         uint32_t value;
-#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-        const bool is_run_ = plane_is_run(in, neblock, value);
-        const unsigned long long prof_load1_ = cimg_cycles();
-        if (is_run_) {
-#else
         if (plane_is_run(in, neblock, value)) {
-#endif
             r.kind = REC_RUN; r.value = (int32_t)value; r.csize = 0;
         } else {
             int need = 0;
             int cb;
-            if constexpr (CODEC == CODEC_BLOSCLZ) cb = blosclz_encode_body(lds, lds + round16(neblock) + 16, neblock, out, neblock, a.p.clevel, need);
-            else cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, a.p.accel, &need, a.dbg, item);
+            if constexpr (CODEC == CODEC_BLOSCLZ) cb = blosclz_encode_body(lds, lds + round16(neblock) + 16, neblock, out, neblock, accel_or_level, need);
+            else cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, accel_or_level, &need, dbg, item);
             if (cb > 0 && cb < neblock) {
                 r.kind = REC_LZ4; r.csize = cb; r.need = need;
             } else {
@@ -885,12 +902,14 @@ struct EncodeStream {
                 wave_copy_l2g(lds, 0, out, neblock);
             }
         }
-#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-        if (a.dbg && __lane_id() == 0) a.dbg[16 * (size_t)item + 14] = prof_load1_ - prof_load0_;
-#endif
-        StreamRec* dst = a.recs + (int64_t)b * spb + s;
-        FOR_LANES(l) { if (l == 0) *dst = r; }
-
+        // ---- the record: its address is worked out again from the arguments (nothing of it was kept alive) -------------
+        {
+            const auto a = fresh(ap);
+            int b, s;
+            item_place(a, item, b, s);
+            StreamRec* dst = a->recs + (int64_t)b * a->p.streams_per_block + s;
+            FOR_LANES(l) { if (l == 0) *dst = r; }
+        }
     }
 };
 

@@ -24,14 +24,16 @@ using namespace cimg;
 extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    EncodeStream<CODEC_LZ4> es(a, lds, (int)blockIdx.x);
+    (void)a;                                   // read through the kernel-argument segment (wave.h: kernarg_ptr)
+    EncodeStream<CODEC_LZ4> es(kernel_args<EncodeArgs>(), lds, (int)blockIdx.x);
     es.run();
 }
 
 extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams_blosclz(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    EncodeStream<CODEC_BLOSCLZ> es(a, lds, (int)blockIdx.x);
+    (void)a;
+    EncodeStream<CODEC_BLOSCLZ> es(kernel_args<EncodeArgs>(), lds, (int)blockIdx.x);
     es.run();
 }
 
@@ -53,9 +55,11 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_lean(DecodeArgs a)
     DecodeLean blk(a, lds, (int)blockIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = (int)(blockDim.x >> 6);
-    blk.phase_a(wave, nwaves);
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
+    blk.phase_a(wave, nwaves);                                   // stamps 1 / 2 inside: header walk done, coded bytes staged
     __syncthreads();
     blk.phase_b(wave, nwaves);
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
@@ -131,6 +135,7 @@ struct cimg_engine {
     // environment knobs are read ONCE, when the engine is created (diagnostics only; none changes results)
     bool verbose = getenv("CIMG_VERBOSE") != nullptr;
     int enc_wgs_limit = getenv("CIMG_ENC_WGS_PER_CU") ? atoi(getenv("CIMG_ENC_WGS_PER_CU")) : 0;
+    int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
     int max_dyn_lds[4] = {0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
@@ -504,6 +509,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     DecodePlan plan;
     int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan);
     if (rc < 0) return e->fail(rc, "decompress batch rejected by the planner (code %d)", rc);
+    if (plan.lds_lean > 0) plan.lds_lean += e->lean_lds_pad;
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
     const size_t st_bytes = sizeof(int32_t) * (size_t)nchunks;
     if ((rc = e->upload_descs(e->descs_dec, e->shadow_dec, plan.descs.data(), desc_bytes))) return rc;
@@ -522,7 +528,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     // for whatever it left.  A batch the lean kernel mostly skips (e.g. every plane LZ4-coded) switches it off for
     // the next 16 batches; the skipped count comes back through the pinned status area.
     const bool stamping = e->stamps;
-    const bool lean = e->lean_hold == 0 && !stamping && plan.lds_lean > 0 && plan.lds_lean < plan.lds_bytes;
+    const bool lean = e->lean_hold == 0 && plan.lds_lean > 0 && plan.lds_lean < plan.lds_bytes;
     if (e->lean_hold > 0 && e->lean_hold < (1 << 30)) e->lean_hold--;
     uint32_t* done = nullptr;
     uint32_t* skipped_dev = nullptr;
@@ -547,7 +553,7 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     const bool timed = e->timing;
     if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
     if (lean) {
-        DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, nullptr,
+        DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, dbg,
                       plan.uniform_nblocks, done, e->done_gen, skipped_dev};
         if (e->verbose && !e->lean_batches) {
             int per_cu = 0;
@@ -560,7 +566,8 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     // The general kernel goes right behind the lean one -- unless the previous lean batch left it nothing to do: then
     // it is only launched (and waited for) if the skipped count that comes back says a block is still undecoded.
     const bool general_now = !lean || e->lean_last_skipped != 0;
-    DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, dbg,
+    // (diagnostic stamps go to the lean launch when there is one: both would write the same slots)
+    DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, (lean && stamping) ? nullptr : dbg,
                   plan.uniform_nblocks, done, e->done_gen, nullptr};
     if (!rc && general_now) {
         if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))

@@ -34,6 +34,9 @@
 #define CIMG_LDS_BASE(passed) (passed)
 typedef uint8_t* cimg_global_u8p;
 #define CIMG_AS_GLOBAL(p) (p)
+// kernel arguments: a plain pointer in the emulator (see the device build)
+template <class T> using kernarg_ptr = const T*;
+template <class T> inline kernarg_ptr<T> fresh(kernarg_ptr<T> p) { return p; }
 typedef volatile uint16_t* cimg_lds_vu16p;
 #define CIMG_AS_LDS_VU16(p) (reinterpret_cast<volatile uint16_t*>(p))
 
@@ -84,6 +87,16 @@ template <class T> inline void lane_gather(const LV<T>& x, const LV<int>& idx, L
     for (int l = 0; l < 64; ++l) tmp[l] = x.v[idx.v[l] & 63];
     for (int l = 0; l < 64; ++l) out.v[l] = tmp[l];
 }
+// out[idx[l]] = x[l]; lanes nobody sends to get 0 (ds_permute).  Colliding senders: any one of them wins.
+template <class T> inline void lane_scatter(const LV<T>& x, const LV<int>& idx, LV<T>& out)
+{
+    T tmp[64];
+    for (int l = 0; l < 64; ++l) tmp[l] = T(0);
+    for (int i = 0; i < 64; ++i) { const int l = emu_lane(i); tmp[idx.v[l] & 63] = x.v[l]; }
+    for (int l = 0; l < 64; ++l) out.v[l] = tmp[l];
+}
+// number of set bits of mask below lane l
+inline int lane_rank(uint64_t mask, int l) { return __builtin_popcountll(mask & ((1ull << l) - 1)); }
 inline uint32_t queue_pop(uint32_t* head) { return (*head)++; }
 inline void atomic_count(uint32_t* p) { ++*p; }
 // value held by lane l-1 (lane 0 keeps its own)
@@ -112,6 +125,13 @@ template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
 // a pointer parameter of an out-of-line device function is generic (flat); this names it global again
 typedef __attribute__((address_space(1))) uint8_t* cimg_global_u8p;
 #define CIMG_AS_GLOBAL(p) ((cimg_global_u8p)(p))
+// Kernel arguments of a persistent kernel are read THROUGH a pointer into the kernel-argument segment (s_load at the
+// point of use) instead of being taken by value: by value the compiler loads every field once at entry and keeps it in
+// SGPRs across the whole codec loop, where scalar registers are the scarce resource (the LZ4 kernel spilled 38 of them).
+// fresh() hides the pointer from the optimizer for a moment so that loads after it are not merged with loads before it.
+template <class T> using kernarg_ptr = const T __attribute__((address_space(4)))*;
+template <class T> __device__ __forceinline__ kernarg_ptr<T> fresh(kernarg_ptr<T> p) { asm volatile("" : "+s"(p)); return p; }
+template <class T> __device__ __forceinline__ kernarg_ptr<T> kernel_args() { return (kernarg_ptr<T>)__builtin_amdgcn_kernarg_segment_ptr(); }
 // volatile accesses are skipped by the compiler's address-space inference and would become FLAT ops
 // (slow, and not ordered with ds_* ops): LDS pointers that must be volatile carry the address space explicitly
 typedef volatile __attribute__((address_space(3))) uint16_t* cimg_lds_vu16p;
@@ -172,6 +192,18 @@ template <class T> CIMG_DEV void lane_gather(const LV<T>& x, const LV<int>& idx,
 {
     static_assert(sizeof(T) == 4, "lane_gather moves one dword");
     out.v = (T)__builtin_amdgcn_ds_bpermute(idx.v << 2, (int)x.v);
+}
+// out[idx[l]] = x[l]; lanes nobody sends to get 0 (ds_permute: LDS crossbar, no memory access).  Every lane sends, so
+// callers give idle lanes a destination nobody reads.
+template <class T> CIMG_DEV void lane_scatter(const LV<T>& x, const LV<int>& idx, LV<T>& out)
+{
+    static_assert(sizeof(T) == 4, "lane_scatter moves one dword");
+    out.v = (T)__builtin_amdgcn_ds_permute(idx.v << 2, (int)x.v);
+}
+// number of set bits of mask below this lane (v_mbcnt_lo / v_mbcnt_hi)
+CIMG_DEV int lane_rank(uint64_t mask, int)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 // one returning device-scope atomic on the queue head (MI355X_MICROARCH.md: 'dequeue', ~0.3-1.1 us)
 CIMG_DEV uint32_t queue_pop(uint32_t* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

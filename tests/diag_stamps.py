@@ -22,7 +22,9 @@ st = st[st[:, 1] > 0]
 t0 = st[:, 1].min()
 T = lambda k: (st[:, 4 * k + 1] - t0) / 100.0
 start, s0, s1, end = T(0), T(1), T(2), T(3)
-print(fam, "decode wgs", len(st), "span us %.1f" % end.max())
-for name, d in (("total", end - start), ("stream0 staged (wave0 phase A)", s0 - start), ("stream1 staged (wave1 phase A)", s1 - start), ("barrier+unshuffle", end - np.maximum(s0, s1))):
+print(fam, "decode wgs", len(st), "span us %.1f" % end.max(), " shader clock MHz %.0f" % np.median((st[:, 12] - st[:, 0]) / np.maximum(st[:, 13] - st[:, 1], 1) * 100))
+print("   start-time percentiles us:", np.percentile(start, [0, 25, 50, 75, 100]).round(1), " end:", np.percentile(end, [0, 25, 50, 75, 100]).round(1))
+lz_end = None
+for name, d in (("total", end - start), ("header walk", s0 - start), ("stage coded bytes", s1 - s0), ("LZ4 + unshuffle", end - s1)):
     print("   %-34s mean %.1f p50 %.1f p90 %.1f max %.1f us" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 print("   avg concurrent WGs per CU %.2f" % ((end - start).sum() / end.max() / 256))

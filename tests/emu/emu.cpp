@@ -16,12 +16,13 @@
 #define EMU_LDS_SLACK 64
 #endif
 
-namespace cimg { int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
+namespace cimg { long g_emu_dec_par = 0, g_emu_dec_serial = 0, g_emu_dec_batches = 0; int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
 
 extern "C" {
 
 void emu_set_write_order(int o) { g_emu_write_order = o; }
+void emu_dec_stats(long* out) { out[0] = g_emu_dec_par; out[1] = g_emu_dec_serial; out[2] = g_emu_dec_batches; g_emu_dec_par = g_emu_dec_serial = g_emu_dec_batches = 0; }
 void emu_stats(long* out, int reset) { out[0] = g_emu_windows; out[1] = g_emu_matches; out[2] = g_emu_collisions; if (reset) g_emu_windows = g_emu_matches = g_emu_collisions = 0; }
 
 struct EmuCParams {
@@ -56,8 +57,8 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
-            if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(ea, lds.data(), w); es.run(); }
-            else { EncodeStream<CODEC_LZ4> es(ea, lds.data(), w); es.run(); }
+            if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
+            else { EncodeStream<CODEC_LZ4> es(&ea, lds.data(), w); es.run(); }
         }
     }
     AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks, nullptr, nullptr};
