@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--family", default="tiled", choices=["tiled", "natural", "random", "zero"])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4],
+                    help="BASELINE.json configuration, counted from 1: 2 = configs[1], 4 x 4096^2 float16 per rank (the headline); "
+                         "4 = configs[3], 64 such images over 8 GPUs = 8 images per rank, with the gather of the finished chunks to rank 0")
     ap.add_argument("--pmc-json", default=None, help="per-launch PMC averages to take roofline.traffic from (profiles/tools/collect.sh)")
     ap.add_argument("--filter", default="shuffle", choices=["shuffle", "bitshuffle", "none"],
                     help="not part of the headline: the reference only uses byte shuffle")
@@ -240,12 +243,16 @@ def main():
 
     # ---- inputs: this rank's 4 channels, resident in HBM ------------------------------------------------
     gen = getattr(synth, args.family + "_channel")
+    images = 8 if args.config == 4 else 1                      # configs[3]: 64 images over 8 ranks
     chans = []
-    for c in range(CHANNELS):
-        if args.family == "zero":
-            chans.append(gen(DTYPE, WIDTH, HEIGHT))
-        else:
-            chans.append(gen(DTYPE, WIDTH, HEIGHT, c=CHANNELS * rank + c))
+    for img in range(images):
+        for c in range(CHANNELS):
+            if args.family == "zero":
+                chans.append(gen(DTYPE, WIDTH, HEIGHT))
+            elif args.config == 4:                              # seeds 1234 + 4 * image + channel
+                chans.append(gen(DTYPE, WIDTH, HEIGHT, c=c, seed=1234 + 4 * (images * rank + img)))
+            else:
+                chans.append(gen(DTYPE, WIDTH, HEIGHT, c=CHANNELS * rank + c))
     host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
     N = host.size
     nchunks = N // CHUNK
@@ -302,6 +309,39 @@ def main():
 
     ktimes = [eng.kernel_time(k) for k in range(4)]
     eng.enable_timing(False)
+
+    # ---- the exchange step of SURVEY.md section 8e (N > 1): every rank's finished chunks travel to rank 0, packed,
+    # point to point with exact sizes (cimg/shard.py: gather_chunks; "nccl" = RCCL send/recv over xGMI).  Timed on its own,
+    # after the codec region: it belongs to a caller that wants the whole result on one device, not to the codec path.
+    exchange = None
+    if dist is not None:
+        from cimg import shard
+        n_items = world * nchunks
+        mine = shard.partition(n_items, world, rank, items_per_group=nchunks)        # rank r owns its own images: items r*nchunks ...
+        sizes_all = shard.gather_sizes(dist, mine, cbytes, n_items, device=red_dev)
+        comp_view = d_comp if not rehearsal else d_comp.cpu()
+        xdev = "cpu" if rehearsal else "cuda"
+        for rep in range(3):                                    # first pass warms the communicator
+            dist.barrier()
+            torch.cuda.synchronize()
+            tx = time.perf_counter()
+            got = shard.gather_chunks(dist, world, rank, mine, comp_view, comp_off, sizes_all, n_items, dst=0,
+                                      items_per_group=nchunks, device=xdev, as_tensor=True)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tx = time.perf_counter() - tx
+        tmax = torch.tensor([tx], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        moved = int(sizes_all.sum() - sizes_all[shard.partition(n_items, world, 0, nchunks)].sum())
+        if rank == 0:
+            whole, offs, szs = got
+            probe = int(mine[0]) if len(mine) else 0
+            ok = whole.numel() == int(sizes_all.sum())
+            exchange = {"what": "finished chunks of every rank gathered to rank 0 (packed compressed bytes, exact sizes, "
+                                "batch_isend_irecv)", "bytes_moved": moved, "seconds": round(float(tmax.item()), 6),
+                        "exchange_GBps": round(moved / float(tmax.item()) / 1e9, 3) if moved else None,
+                        "backend": "gloo (rehearsal on one GPU: meaningless as a number)" if rehearsal else "nccl (RCCL over xGMI)",
+                        "complete": bool(ok)}
     if not torch.equal(d_out, d_raw):
         print("bench.py: pixels differ after the timed region", file=sys.stderr)
         sys.exit(3)
@@ -330,7 +370,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{CHANNELS}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + {FILTER_TEXT[args.filter]}, "
+            "config": {"workload": f"{'BASELINE configs[3] share of one rank: 8 images x ' if args.config == 4 else ''}"
+                                   f"{len(chans)}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + {FILTER_TEXT[args.filter]}, "
                                    f"32 KiB blocks, 4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks, {2 * N // BLOCK} streams), "
                                    f"device-resident, family={args.family}",
                        "element_dtype": "float16", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(C),
@@ -346,9 +387,10 @@ def main():
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": dec_traffic,
                                 "frac": round((C + N) / dec_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if dec_avg_s > 0 else None},
             "kernels": kernels,
+            "exchange": exchange,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
         }
-        if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle":
+        if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle" and args.config == 2:
             out["cpu_baseline"] = cpu_baseline(host, budget_s=10.0, policy="all_cores")
             # the reference's own call structure (serial chunks, hw/2 threads inside a chunk for encode, 1 thread decode)
             out["cpu_baseline_reference_policy"] = cpu_baseline(host, budget_s=8.0, policy="reference")

@@ -1,9 +1,9 @@
 """Sharding of independent chunks / channels over ranks.
 
 Chunks are self-contained blosc2 buffers, so the codec path needs no data-path collective: every rank
-compresses / decompresses its own items with its own engine.  The only exchanges are tiny: the
-max-over-ranks of the elapsed time, and the per-item compressed sizes so that every rank (or rank 0)
-knows the global layout.  Works with any torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo"
+compresses / decompresses its own items with its own engine.  The small exchanges are the
+max-over-ranks of the elapsed time and the per-item compressed sizes (every rank learns the global layout); the one
+payload exchange -- finished chunks to the rank that wants the whole image -- is gather_chunks below.  Works with any torch.distributed backend ("nccl" = RCCL on the GPU box, "gloo"
 in the CPU tests).
 """
 import numpy as np
@@ -48,43 +48,53 @@ def max_over_ranks(dist, seconds, device="cpu"):
 
 
 def gather_chunks(dist, world, rank, local_idx, local_buf, local_off, sizes_all, n_items, dst=0, items_per_group=1,
-                  device="cpu"):
+                  device="cpu", as_tensor=False):
     """The one real exchange step of SURVEY.md section 8e: owner ranks send their finished chunks to `dst`.
 
     local_buf   uint8 torch tensor (or numpy array) holding this rank's chunks, chunk k of `local_idx` at
                 local_off[k] with length sizes_all[local_idx[k]]
     sizes_all   result of gather_sizes() (every rank knows every chunk's compressed size)
-    Returns on `dst` a list of n_items uint8 numpy arrays in global chunk order, elsewhere None.
-    Payloads travel packed back to back (only compressed bytes, C/world per rank), padded to the largest
-    per-rank total because gather needs equal shapes; with backend "nccl" this is RCCL send/recv over xGMI.
-    It is a property of a caller that wants all chunks on one device -- bench.py never calls it.
+    Every rank packs its chunks back to back (compressed bytes only) and the exchange is point to point with EXACT
+    sizes: `dst` posts one receive per owner rank, every other rank one send (batch_isend_irecv; with backend "nccl"
+    that is one RCCL group of send/recv over the direct xGMI links -- all-to-one, no ring, nothing padded to the largest
+    rank).  Returns on `dst` the chunks in global order -- a list of uint8 numpy arrays, or with as_tensor=True the
+    tuple (packed uint8 tensor on `device`, int64 offsets[n_items], int64 sizes[n_items]) -- and None elsewhere.
     """
     import torch
     sizes_all = np.asarray(sizes_all, dtype=np.int64)
     owners = [partition(n_items, world, r, items_per_group) for r in range(world)]
     totals = [int(sizes_all[o].sum()) for o in owners]
-    pad = max(totals + [1])
     if not torch.is_tensor(local_buf):
         local_buf = torch.as_tensor(np.ascontiguousarray(local_buf).view(np.uint8))
-    packed = torch.zeros(pad, dtype=torch.uint8, device=device)
-    at = 0
-    for k, g in enumerate(np.asarray(local_idx, dtype=np.int64)):
-        n = int(sizes_all[g])
-        packed[at:at + n] = local_buf[int(local_off[k]):int(local_off[k]) + n].to(device)
-        at += n
-    if dist is None or not dist.is_initialized() or world == 1:
-        parts = [packed]
-    else:
-        parts = [torch.empty(pad, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-        dist.gather(packed, gather_list=parts, dst=dst)
+    local_idx = np.asarray(local_idx, dtype=np.int64)
+    pieces = [local_buf[int(local_off[k]):int(local_off[k]) + int(sizes_all[g])] for k, g in enumerate(local_idx)]
+    packed = (torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.uint8)).to(device)
+    assert packed.numel() == totals[rank]
+    multi = dist is not None and dist.is_initialized() and world > 1
+    parts = None
+    if rank == dst:
+        parts = [packed if r == dst else torch.empty(totals[r], dtype=torch.uint8, device=device) for r in range(world)]
+    if multi:
+        ops = []
+        if rank == dst:
+            ops = [dist.P2POp(dist.irecv, parts[r], r) for r in range(world) if r != dst and totals[r] > 0]
+        elif totals[rank] > 0:
+            ops = [dist.P2POp(dist.isend, packed, dst)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
     if rank != dst:
         return None
-    out = [None] * n_items
+    # global order: chunk g lives in its owner's part at the running offset of that part
+    part_base = np.concatenate([[0], np.cumsum(totals[:-1])]).astype(np.int64)
+    offsets = np.zeros(n_items, dtype=np.int64)
     for r in range(world):
-        host = parts[r].cpu().numpy()
-        at = 0
+        at = int(part_base[r])
         for g in owners[r]:
-            n = int(sizes_all[g])
-            out[int(g)] = host[at:at + n].copy()
-            at += n
-    return out
+            offsets[int(g)] = at
+            at += int(sizes_all[g])
+    whole = torch.cat(parts) if world > 1 else parts[0]
+    if as_tensor:
+        return whole, offsets, sizes_all.copy()
+    host = whole.cpu().numpy()
+    return [host[int(offsets[g]):int(offsets[g]) + int(sizes_all[g])].copy() for g in range(n_items)]

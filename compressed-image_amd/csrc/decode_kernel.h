@@ -518,8 +518,8 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                 uint64_t parmask = ballot(par);
                 if (popc64(parmask) < 3) parmask = 0;            // one or two: the in-order loop below is cheaper (latency of the gathers)
                 if (parmask) {
-                    // their descriptors are made dense (lane k = k-th such match), then EIGHT MATCHES PER STEP: eight lanes
-                    // per match, eight bytes per lane -- one store instruction moves up to 64 bytes of eight matches
+                    // their descriptors are made dense (lane k = k-th such match), then SIXTEEN MATCHES PER STEP: four lanes
+                    // per match, sixteen bytes per lane -- one store instruction moves a byte of every lane of sixteen matches
                     const int P = popc64(parmask);                       // <= 22: a sequence is at least three bytes
                     LV<int> rank, d0, d1, D0, D1;
                     FOR_LANES(l) {
@@ -529,32 +529,37 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                     }
                     lane_scatter(d0, rank, D0);
                     lane_scatter(d1, rank, D1);
-                    for (int g = 0; g < P; g += 8) {
+                    for (int g = 0; g < P; g += 16) {
+                        // sixteen matches per step: four lanes per match, sixteen bytes per lane
                         LV<int> who, e0, e1;
-                        FOR_LANES(l) { who[l] = g + (l >> 3); }
+                        FOR_LANES(l) { who[l] = g + (l >> 2); }
                         lane_gather(D0, who, e0);
                         lane_gather(D1, who, e1);
-                        LV<uint32_t> w0, w1;
+                        LV<u128> w;
                         FOR_LANES(l) {
                             const bool act = who[l] < P;
                             const bool f = (e1[l] >> 18) & 1;
-                            const int a = act ? (e1[l] & 0x3FFFF) + (f ? 0 : (l & 7) * 8) : base;
-                            const uint32_t x0 = lds_ld32u(lds, a), x1 = lds_ld32u(lds, a + 4);
+                            const int sa = act ? (e1[l] & 0x3FFFF) + (f ? 0 : (l & 3) * 16) : base;
+                            const int a = sa & ~3;
+                            const uint32_t sh = (uint32_t)sa & 3u;
+                            const uint32_t q0 = *reinterpret_cast<const uint32_t*>(lds + a);
+                            const uint32_t q1 = *reinterpret_cast<const uint32_t*>(lds + a + 4);
+                            const uint32_t q2 = *reinterpret_cast<const uint32_t*>(lds + a + 8);
+                            const uint32_t q3 = *reinterpret_cast<const uint32_t*>(lds + a + 12);
+                            const uint32_t q4 = *reinterpret_cast<const uint32_t*>(lds + a + 16);
+                            const uint32_t x0 = alignbyte(q1, q0, sh);
                             const uint32_t fb = (x0 & 0xFF) * 0x01010101u;
-                            w0[l] = f ? fb : x0;
-                            w1[l] = f ? fb : x1;
+                            w[l].x = f ? fb : x0;
+                            w[l].y = f ? fb : alignbyte(q2, q1, sh);
+                            w[l].z = f ? fb : alignbyte(q3, q2, sh);
+                            w[l].w = f ? fb : alignbyte(q4, q3, sh);
                         }
                         FOR_LANES_W(l) {
-                            const int rem = who[l] < P ? (e0[l] >> 18) - (l & 7) * 8 : 0;
-                            uint8_t* d = lds + (e0[l] & 0x3FFFF) + (l & 7) * 8;
-                            if (rem > 0) d[0] = (uint8_t)w0[l];
-                            if (rem > 1) d[1] = (uint8_t)(w0[l] >> 8);
-                            if (rem > 2) d[2] = (uint8_t)(w0[l] >> 16);
-                            if (rem > 3) d[3] = (uint8_t)(w0[l] >> 24);
-                            if (rem > 4) d[4] = (uint8_t)w1[l];
-                            if (rem > 5) d[5] = (uint8_t)(w1[l] >> 8);
-                            if (rem > 6) d[6] = (uint8_t)(w1[l] >> 16);
-                            if (rem > 7) d[7] = (uint8_t)(w1[l] >> 24);
+                            const int rem = who[l] < P ? (e0[l] >> 18) - (l & 3) * 16 : 0;
+                            uint8_t* d = lds + (e0[l] & 0x3FFFF) + (l & 3) * 16;
+                            const uint32_t v[4] = {w[l].x, w[l].y, w[l].z, w[l].w};
+                            CIMG_UNROLL
+                            for (int k = 0; k < 16; k++) { if (rem > k) d[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3))); }
                         }
                     }
                 }

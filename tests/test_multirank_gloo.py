@@ -51,6 +51,17 @@ def _worker(rank, world, port, out):
             local[k * stride:k * stride + b.size] = b
         got = shard.gather_chunks(dist, world, rank, mine, local, [k * stride for k in range(len(mine))], full, n,
                                   dst=0, items_per_group=4)
+        # the same exchange handing back ONE packed tensor + offsets (what bench.py --config 4 uses): nothing is padded to
+        # the largest rank -- rank 0 owns 8 chunks, rank 1 four -- and the bytes are those of the list form
+        packed = shard.gather_chunks(dist, world, rank, mine, local, [k * stride for k in range(len(mine))], full, n,
+                                     dst=0, items_per_group=4, as_tensor=True)
+        if rank == 0:
+            whole, offs, szs = packed
+            assert whole.numel() == int(np.asarray(full).sum()) and szs.tolist() == list(full)
+            for i in range(n):
+                assert whole[int(offs[i]):int(offs[i]) + int(szs[i])].numpy().tobytes() == got[i].tobytes()
+        else:
+            assert packed is None
         digest = None
         if rank == 0:
             assert len(got) == n and all(g is not None for g in got)
