@@ -107,6 +107,11 @@ struct EventPair {
 struct cimg_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    // host-buffer calls: pixels / chunks of the NEXT group travel over PCIe (copy streams) while the kernels of the
+    // current group run (stream) and the results of the PREVIOUS one travel back
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done = nullptr;
+    int64_t host_group_bytes = getenv("CIMG_HOST_GROUP_MIB") ? atoll(getenv("CIMG_HOST_GROUP_MIB")) << 20 : 16ll << 20;   // measured: 8 / 16 / 32 / 64 MiB -> 45.9 / 46.6 / 44.3 / 39.0 GB/s
     DevBuf descs_enc, descs_dec, recs, layout, scratch, stage_raw, stage_comp, dbg, queue;
     // chunk descriptors last uploaded for encode / decode: a batch with the same geometry as the previous one
     // (the steady state of an image pipeline) skips the upload
@@ -149,6 +154,13 @@ struct cimg_engine {
     double total_ms[CIMG_K_COUNT] = {0, 0, 0, 0};
     int64_t launches[CIMG_K_COUNT] = {0, 0, 0, 0};
     std::string err;
+    // a decode batch between decompress_launch() and decompress_finish()
+    struct DecodeFlight {
+        bool lean = false, general_now = true, timed = false;
+        int32_t nchunks = 0, total_blocks = 0, lds_bytes = 0;
+        size_t st_bytes = 0;
+        DecodeArgs da{};
+    } dflight;
 
     int fail(int code, const char* fmt, ...)
     {
@@ -313,6 +325,10 @@ int cimg_engine_create(int device, cimg_engine** out)
     eng->device = device;
     eng->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&eng->s_h2d, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&eng->s_d2h, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&eng->ev_h2d[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&eng->ev_done, hipEventDisableTiming);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete eng; return ERR_FAILURE; }
     *out = eng;
     return 0;
@@ -330,6 +346,10 @@ void cimg_engine_destroy(cimg_engine* e)
     for (PinBuf* b : {&e->h_descs, &e->h_out})
         if (b->p) (void)hipHostFree(b->p);
     (void)hipStreamDestroy(e->stream);
+    if (e->s_h2d) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamDestroy(e->s_h2d); }
+    if (e->s_d2h) { (void)hipStreamSynchronize(e->s_d2h); (void)hipStreamDestroy(e->s_d2h); }
+    for (int k = 0; k < 2; k++) if (e->ev_h2d[k]) (void)hipEventDestroy(e->ev_h2d[k]);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     delete e;
 }
 
@@ -423,13 +443,11 @@ static HostCParams to_host(const cimg_cparams* p)
     return h;
 }
 
-int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
-                               const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
-                               void* d_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
+// the kernels of one compress batch, enqueued on the engine's stream; compress_finish() waits and fetches the sizes
+static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                           const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
+                           void* d_comp, const int64_t* comp_off, const int32_t* destsize)
 {
-    std::lock_guard<std::recursive_mutex> lock_(e->mu);
-    if (nchunks <= 0) return 0;
-    if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
     e->begin_batch(0);
     EncodePlan plan;
@@ -491,19 +509,34 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
     if ((rc = e->launch(CIMG_K_LAYOUT, cimg_layout_chunks, aa, nchunks, 64, 0))) return rc;
     e->queue_clean = true;                        // chunk 0's layout wave zeroes both queue heads for the next batch
     if ((rc = e->launch(CIMG_K_EMIT, cimg_emit_blocks, aa, plan.total_blocks, 256, 0))) return rc;
+    return 0;
+}
+
+static int compress_finish(cimg_engine* e, int32_t nchunks, int32_t* cbytes)
+{
+    int rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
     const ChunkLayout* lay = (const ChunkLayout*)e->h_out.p;
     for (int i = 0; i < nchunks; i++) cbytes[i] = lay[i].cbytes;
     return 0;
 }
 
-int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
-                                 const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
-                                 int32_t* status)
+int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                               const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
+                               void* d_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
 {
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
-    if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize);
+    return rc ? rc : compress_finish(e, nchunks, cbytes);
+}
+
+// the kernels of one decode batch, enqueued on the engine's stream; decompress_finish() waits, launches the general
+// kernel late if the lean one left blocks behind, and collects the status words
+static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
+                             const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off)
+{
     (void)hipSetDevice(e->device);
     e->begin_batch(1);
     DecodePlan plan;
@@ -574,7 +607,21 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);
     }
     if (timed) { e->timing = true; (void)hipEventRecord(ev.b, e->stream); e->pending[CIMG_K_DECODE].push_back(ev); }
-    if (rc) return rc;
+    e->dflight.lean = lean; e->dflight.general_now = general_now; e->dflight.timed = timed;
+    e->dflight.nchunks = nchunks; e->dflight.total_blocks = plan.total_blocks; e->dflight.lds_bytes = plan.lds_bytes;
+    e->dflight.st_bytes = st_bytes; e->dflight.da = da;
+    return rc;
+}
+
+static int decompress_finish(cimg_engine* e, int32_t* status)
+{
+    const cimg_engine::DecodeFlight& f = e->dflight;
+    const bool lean = f.lean, general_now = f.general_now, timed = f.timed;
+    const int32_t nchunks = f.nchunks;
+    const DecodeArgs da = f.da;
+    struct { int32_t total_blocks, lds_bytes; } plan{f.total_blocks, f.lds_bytes};
+    volatile uint32_t* skipped_host = (volatile uint32_t*)((uint8_t*)e->h_out.p + ((f.st_bytes + 15) & ~(size_t)15));
+    int rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
     if (lean) {
         const uint32_t skipped = *skipped_host;
@@ -604,14 +651,81 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     return 0;
 }
 
-// ---- host-resident batches: stage through device buffers owned by the engine -----------------------
-int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
-                                   const int64_t* raw_off, const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
+int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
+                                 const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
+                                 int32_t* status)
 {
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
-    e->fetch_off.clear();
     if (nchunks <= 0) return 0;
-    if (!h_raw || !raw_off || !nbytes || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off);
+    return rc ? rc : decompress_finish(e, status);
+}
+
+// ---- host-resident batches: stage through device buffers owned by the engine -----------------------
+// The batch is cut into groups of about 16 MiB of pixels.  While the kernels of group g run on the engine's stream, the
+// pixels (or chunks) of group g + 1 travel host -> device on a second stream and the results of group g - 1 device -> host
+// on a third: PCIe Gen5 moves both directions at once, and the kernels hide behind the copies.  (Launch first, copy
+// second: from pageable memory a hipMemcpyAsync keeps the calling thread busy staging, so the kernels must already be
+// queued when it starts.)
+namespace {
+
+struct Groups {
+    std::vector<int> first;          // first chunk of every group, plus nchunks at the end
+    void cut(int nchunks, const int32_t* bytes, int64_t target)
+    {
+        first.assign(1, 0);
+        int64_t acc = 0;
+        for (int i = 0; i < nchunks; i++) {
+            acc += bytes[i];
+            if (acc >= target && i + 1 < nchunks) { first.push_back(i + 1); acc = 0; }
+        }
+        first.push_back(nchunks);
+    }
+    int count() const { return (int)first.size() - 1; }
+};
+
+// host -> device copy of chunks [a, b): one transfer when they are contiguous on both sides
+int copy_in(cimg_engine* e, hipStream_t st, uint8_t* dev, const int64_t* dev_off, const uint8_t* host, const int64_t* host_off,
+            const int32_t* len, int a, int b, const char* what)
+{
+    bool contiguous = true;
+    for (int i = a + 1; i < b; i++)
+        if (host_off[i] != host_off[i - 1] + len[i - 1] || dev_off[i] != dev_off[i - 1] + len[i - 1]) { contiguous = false; break; }
+    if (contiguous) {
+        int64_t total = 0;
+        for (int i = a; i < b; i++) total += len[i];
+        return total ? e->hip(hipMemcpyAsync(dev + dev_off[a], host + host_off[a], (size_t)total, hipMemcpyHostToDevice, st), what) : 0;
+    }
+    for (int i = a; i < b; i++)
+        if (len[i] > 0)
+            if (int rc = e->hip(hipMemcpyAsync(dev + dev_off[i], host + host_off[i], (size_t)len[i], hipMemcpyHostToDevice, st), what)) return rc;
+    return 0;
+}
+
+int copy_out(cimg_engine* e, hipStream_t st, uint8_t* host, const int64_t* host_off, const uint8_t* dev, const int64_t* dev_off,
+             const int32_t* len, int a, int b, const char* what)
+{
+    bool contiguous = true;
+    for (int i = a + 1; i < b; i++)
+        if (host_off[i] != host_off[i - 1] + len[i - 1] || dev_off[i] != dev_off[i - 1] + len[i - 1]) { contiguous = false; break; }
+    if (contiguous) {
+        int64_t total = 0;
+        for (int i = a; i < b; i++) total += len[i];
+        return total ? e->hip(hipMemcpyAsync(host + host_off[a], dev + dev_off[a], (size_t)total, hipMemcpyDeviceToHost, st), what) : 0;
+    }
+    for (int i = a; i < b; i++)
+        if (len[i] > 0)
+            if (int rc = e->hip(hipMemcpyAsync(host + host_off[i], dev + dev_off[i], (size_t)len[i], hipMemcpyDeviceToHost, st), what)) return rc;
+    return 0;
+}
+
+// compress from host pixels; chunks stay in the device staging area, and go to h_comp as well when it is given
+int compress_host_pipeline(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw, const int64_t* raw_off,
+                           const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes, void* h_comp, const int64_t* comp_off)
+{
+    e->fetch_off.clear();
+    if (!p || !h_raw || !raw_off || !nbytes || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
     (void)hipSetDevice(e->device);
     // pack pixels back to back (16-byte aligned) and give every chunk its full destsize on the device
     std::vector<int64_t> d_raw_off((size_t)nchunks), d_comp_off((size_t)nchunks);
@@ -630,18 +744,56 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
     int rc;
     if ((rc = e->reserve(e->stage_raw, (size_t)raw_total + 64))) return rc;
     if ((rc = e->reserve(e->stage_comp, (size_t)comp_total + 64))) return rc;
+    Groups G;
+    G.cut(nchunks, nbytes, e->host_group_bytes);
     const uint8_t* hr = (const uint8_t*)h_raw;
-    if (contiguous) {
-        if ((rc = e->hip(hipMemcpyAsync(e->stage_raw.p, hr + raw_off[0], (size_t)raw_total, hipMemcpyHostToDevice, e->stream), "pixels H2D"))) return rc;
-    } else {
-        for (int i = 0; i < nchunks; i++)
-            if ((rc = e->hip(hipMemcpyAsync((uint8_t*)e->stage_raw.p + d_raw_off[(size_t)i], hr + raw_off[i], (size_t)nbytes[i], hipMemcpyHostToDevice, e->stream), "pixels H2D"))) return rc;
+    uint8_t* sr = (uint8_t*)e->stage_raw.p;
+    uint8_t* sc = (uint8_t*)e->stage_comp.p;
+    const int ng = G.count();
+    if (ng == 1) {
+        // a small batch (the blosc2_compress_ctx shim: one chunk) has nothing to overlap: one stream, no events
+        if ((rc = copy_in(e, e->stream, sr, d_raw_off.data(), hr, raw_off, nbytes, 0, nchunks, "pixels H2D"))) return rc;
+        rc = compress_launch(e, p, nchunks, sr, d_raw_off.data(), nbytes, sc, d_comp_off.data(), destsize);
+        const int frc = compress_finish(e, nchunks, cbytes);
+        if (rc || frc) return rc ? rc : frc;
+        if (h_comp) {
+            if ((rc = copy_out(e, e->stream, (uint8_t*)h_comp, comp_off, sc, d_comp_off.data(), cbytes, 0, nchunks, "chunk D2H"))) return rc;
+            if ((rc = cimg_engine_synchronize(e))) return rc;
+        }
+        e->fetch_off = std::move(d_comp_off);
+        e->fetch_len.assign(cbytes, cbytes + nchunks);
+        return 0;
     }
-    rc = cimg_compress_batch_device(e, p, nchunks, e->stage_raw.p, d_raw_off.data(), nbytes, e->stage_comp.p, d_comp_off.data(), destsize, cbytes);
-    if (rc) return rc;
+    if ((rc = copy_in(e, e->s_h2d, sr, d_raw_off.data(), hr, raw_off, nbytes, G.first[0], G.first[1], "pixels H2D"))) return rc;
+    if ((rc = e->hip(hipEventRecord(e->ev_h2d[0], e->s_h2d), "event record"))) return rc;
+    for (int g = 0; g < ng; g++) {
+        const int a = G.first[(size_t)g], b = G.first[(size_t)g + 1];
+        if ((rc = e->hip(hipStreamWaitEvent(e->stream, e->ev_h2d[g & 1], 0), "stream wait"))) return rc;
+        rc = compress_launch(e, p, b - a, sr, d_raw_off.data() + a, nbytes + a, sc, d_comp_off.data() + a, destsize + a);
+        if (!rc && g + 1 < ng) {
+            rc = copy_in(e, e->s_h2d, sr, d_raw_off.data(), hr, raw_off, nbytes, b, G.first[(size_t)g + 2], "pixels H2D");
+            if (!rc) rc = e->hip(hipEventRecord(e->ev_h2d[(g + 1) & 1], e->s_h2d), "event record");
+        }
+        const int frc = compress_finish(e, b - a, cbytes + a);          // always: nothing may stay in flight on an error path
+        if (rc || frc) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamSynchronize(e->s_d2h); return rc ? rc : frc; }
+        if (h_comp)
+            if ((rc = copy_out(e, e->s_d2h, (uint8_t*)h_comp, comp_off, sc, d_comp_off.data(), cbytes, a, b, "chunk D2H"))) { (void)hipStreamSynchronize(e->s_d2h); return rc; }
+    }
+    if (h_comp) { if ((rc = e->hip(hipStreamSynchronize(e->s_d2h), "chunk D2H"))) return rc; }
     e->fetch_off = std::move(d_comp_off);
     e->fetch_len.assign(cbytes, cbytes + nchunks);
     return 0;
+}
+
+}  // namespace
+
+int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
+                                   const int64_t* raw_off, const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    e->fetch_off.clear();
+    if (nchunks <= 0) return 0;
+    return compress_host_pipeline(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes, nullptr, nullptr);
 }
 
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp, const int64_t* comp_off)
@@ -651,13 +803,10 @@ int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp
     if (!h_comp || !comp_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     if ((size_t)nchunks != e->fetch_off.size()) return e->fail(ERR_INVALID_PARAM, "no compressed batch of %d chunks is waiting to be fetched", nchunks);
     (void)hipSetDevice(e->device);
-    int rc;
-    uint8_t* hc = (uint8_t*)h_comp;
-    for (int i = 0; i < nchunks; i++)
-        if (e->fetch_len[(size_t)i] > 0)
-            if ((rc = e->hip(hipMemcpyAsync(hc + comp_off[i], (uint8_t*)e->stage_comp.p + e->fetch_off[(size_t)i], (size_t)e->fetch_len[(size_t)i], hipMemcpyDeviceToHost, e->stream), "chunk D2H"))) return rc;
+    int rc = copy_out(e, e->s_d2h, (uint8_t*)h_comp, comp_off, (const uint8_t*)e->stage_comp.p, e->fetch_off.data(), e->fetch_len.data(), 0, nchunks, "chunk D2H");
     e->fetch_off.clear();
-    return cimg_engine_synchronize(e);
+    const int src = e->hip(hipStreamSynchronize(e->s_d2h), "chunk D2H");
+    return rc ? rc : src;
 }
 
 int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,
@@ -667,9 +816,9 @@ int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchu
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!h_comp || !comp_off) return e->fail(ERR_INVALID_PARAM, "null argument");
-    const int rc = cimg_compress_batch_host_begin(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes);
-    if (rc) return rc;
-    return cimg_compress_batch_host_fetch(e, nchunks, h_comp, comp_off);
+    const int rc = compress_host_pipeline(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes, h_comp, comp_off);
+    e->fetch_off.clear();                                  // delivered: nothing is left to fetch
+    return rc;
 }
 
 int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks, const void* h_comp, const int64_t* comp_off,
@@ -690,6 +839,7 @@ int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void
     std::vector<int64_t> d_comp_off((size_t)nchunks), d_raw_off((size_t)nchunks);
     std::vector<int32_t> nb((size_t)nchunks), bs((size_t)nchunks), cb((size_t)nchunks);
     int64_t comp_total = 0, raw_total = 0;
+    bool dense = true;                                     // pixels back to back on the host: keep them so on the device
     for (int i = 0; i < nchunks; i++) {
         const uint8_t* c = hc + comp_off[i];
         int32_t n, cbv, b;
@@ -700,28 +850,62 @@ int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void
         if (comp_size && cbv > comp_size[i]) return e->fail(ERR_READ_BUFFER, "chunk %d: header says %d compressed bytes, the buffer holds %d", i, cbv, comp_size[i]);
         if (n > raw_capacity[i]) return e->fail(ERR_WRITE_BUFFER, "chunk %d: needs %d bytes, buffer has %d", i, n, raw_capacity[i]);
         nb[(size_t)i] = n; bs[(size_t)i] = b; cb[(size_t)i] = cbv;
-        d_comp_off[(size_t)i] = comp_total; comp_total += ((int64_t)cbv + 63) & ~63ll;
-        d_raw_off[(size_t)i] = raw_total; raw_total += ((int64_t)n + 15) & ~15ll;
+        if (i > 0 && raw_off[i] != raw_off[i - 1] + nb[(size_t)i - 1]) dense = false;
+    }
+    for (int i = 0; i < nchunks; i++) {
+        d_comp_off[(size_t)i] = comp_total; comp_total += ((int64_t)cb[(size_t)i] + 63) & ~63ll;
+        d_raw_off[(size_t)i] = raw_total; raw_total += dense ? (int64_t)nb[(size_t)i] : (((int64_t)nb[(size_t)i] + 15) & ~15ll);
     }
     int rc;
     if ((rc = e->reserve(e->stage_comp, (size_t)comp_total + 64))) return rc;
     if ((rc = e->reserve(e->stage_raw, (size_t)raw_total + 64))) return rc;
-    for (int i = 0; i < nchunks; i++)
-        if ((rc = e->hip(hipMemcpyAsync((uint8_t*)e->stage_comp.p + d_comp_off[(size_t)i], hc + comp_off[i], (size_t)cb[(size_t)i], hipMemcpyHostToDevice, e->stream), "chunk H2D"))) return rc;
-    // chunks with nbytes == 0 carry no blocks; blocksize must still be positive for the planner
-    std::vector<int32_t> st((size_t)nchunks, 0);
-    const int drc = cimg_decompress_batch_device(e, nchunks, e->stage_comp.p, d_comp_off.data(), nb.data(), bs.data(), e->stage_raw.p, d_raw_off.data(), st.data());
-    if (status) memcpy(status, st.data(), sizeof(int32_t) * (size_t)nchunks);
-    if (drc == ERR_FAILURE) return drc;                       // the launch itself failed
-    // chunks that decoded cleanly are still delivered when a neighbour in the batch is damaged
-    const std::string chunk_error = e->err;
+    Groups G;
+    G.cut(nchunks, nb.data(), e->host_group_bytes);
+    const int ng = G.count();
+    uint8_t* sr = (uint8_t*)e->stage_raw.p;
+    uint8_t* sc = (uint8_t*)e->stage_comp.p;
     uint8_t* hr = (uint8_t*)h_raw;
-    for (int i = 0; i < nchunks; i++)
-        if (nb[(size_t)i] > 0 && st[(size_t)i] == 0)
-            if ((rc = e->hip(hipMemcpyAsync(hr + raw_off[i], (uint8_t*)e->stage_raw.p + d_raw_off[(size_t)i], (size_t)nb[(size_t)i], hipMemcpyDeviceToHost, e->stream), "pixels D2H"))) return rc;
-    if ((rc = cimg_engine_synchronize(e))) return rc;
-    if (drc) e->err = chunk_error;
-    return drc;
+    std::vector<int32_t> st((size_t)nchunks, 0);
+    std::vector<int32_t> deliver((size_t)nchunks, 0);
+    if (ng == 1) {
+        if ((rc = copy_in(e, e->stream, sc, d_comp_off.data(), hc, comp_off, cb.data(), 0, nchunks, "chunk H2D"))) return rc;
+        rc = decompress_launch(e, nchunks, sc, d_comp_off.data(), nb.data(), bs.data(), sr, d_raw_off.data());
+        int drc = rc;
+        if (!rc || rc != ERR_FAILURE) { const int frc = decompress_finish(e, st.data()); if (!drc) drc = frc; }
+        if (status) memcpy(status, st.data(), sizeof(int32_t) * (size_t)nchunks);
+        if (drc == ERR_FAILURE) return drc;
+        const std::string chunk_error1 = e->err;
+        for (int i = 0; i < nchunks; i++) deliver[(size_t)i] = (nb[(size_t)i] > 0 && st[(size_t)i] == 0) ? nb[(size_t)i] : 0;
+        if ((rc = copy_out(e, e->stream, hr, raw_off, sr, d_raw_off.data(), deliver.data(), 0, nchunks, "pixels D2H"))) return rc;
+        if ((rc = cimg_engine_synchronize(e))) return rc;
+        if (drc) e->err = chunk_error1;
+        return drc;
+    }
+    if ((rc = copy_in(e, e->s_h2d, sc, d_comp_off.data(), hc, comp_off, cb.data(), G.first[0], G.first[1], "chunk H2D"))) return rc;
+    if ((rc = e->hip(hipEventRecord(e->ev_h2d[0], e->s_h2d), "event record"))) return rc;
+    int first_bad = 0;
+    std::string chunk_error;
+    for (int g = 0; g < ng; g++) {
+        const int a = G.first[(size_t)g], b = G.first[(size_t)g + 1];
+        if ((rc = e->hip(hipStreamWaitEvent(e->stream, e->ev_h2d[g & 1], 0), "stream wait"))) return rc;
+        rc = decompress_launch(e, b - a, sc, d_comp_off.data() + a, nb.data() + a, bs.data() + a, sr, d_raw_off.data() + a);
+        int crc = 0;
+        if (g + 1 < ng) {
+            crc = copy_in(e, e->s_h2d, sc, d_comp_off.data(), hc, comp_off, cb.data(), b, G.first[(size_t)g + 2], "chunk H2D");
+            if (!crc) crc = e->hip(hipEventRecord(e->ev_h2d[(g + 1) & 1], e->s_h2d), "event record");
+        }
+        int drc = rc;
+        if (!rc || rc != ERR_FAILURE) { const int frc = decompress_finish(e, st.data() + a); if (!drc) drc = frc; }
+        if (drc == ERR_FAILURE || crc) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamSynchronize(e->s_d2h); return crc ? crc : drc; }
+        if (drc && !first_bad) { first_bad = drc; chunk_error = e->err; }
+        // chunks that decoded cleanly are still delivered when a neighbour in the batch is damaged
+        for (int i = a; i < b; i++) deliver[(size_t)i] = (nb[(size_t)i] > 0 && st[(size_t)i] == 0) ? nb[(size_t)i] : 0;
+        if ((rc = copy_out(e, e->s_d2h, hr, raw_off, sr, d_raw_off.data(), deliver.data(), a, b, "pixels D2H"))) { (void)hipStreamSynchronize(e->s_d2h); return rc; }
+    }
+    if (status) memcpy(status, st.data(), sizeof(int32_t) * (size_t)nchunks);
+    if ((rc = e->hip(hipStreamSynchronize(e->s_d2h), "pixels D2H"))) return rc;
+    if (first_bad) e->err = chunk_error;
+    return first_bad;
 }
 
 }  // extern "C"
