@@ -52,6 +52,8 @@ struct EncodeArgs {
     uint64_t* dbg;            // diagnostics only: per-item time stamps (nullptr in production)
     uint32_t* queue;          // work-queue head, zeroed before the launch
     int32_t uniform_nblocks;  // > 0: every chunk has this many blocks
+    int32_t block_items;      // 1 (split launch only): a work item is a whole BLOCK -- read from HBM once, its byte planes
+                              // encoded one after the other by the same wave (the planes that wait sit in registers)
 };
 
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
@@ -66,9 +68,15 @@ inline int encode_lds_bytes(int stream_bytes, int compcode = CODEC_LZ4)
 // pull items from a queue.  Split launch: item i is plane (spb-1 - i / total_blocks) of block
 // i % total_blocks -- most significant byte planes (smooth, many matches, slow) first, noisy low planes
 // last (longest-processing-time-first).  Unsplit launch: item i is block i.
-CIMG_HD int encode_items(int total_blocks, int streams_per_block, bool split)
+CIMG_HD int encode_items(int total_blocks, int streams_per_block, bool split, bool block_items = false)
 {
-    return split ? total_blocks * streams_per_block : total_blocks;
+    return (split && !block_items) ? total_blocks * streams_per_block : total_blocks;
+}
+// A split launch can hand out whole blocks when every full block is the standard 32 KiB of a 2- or 4-byte type, byte
+// shuffled: then the planes that wait for their turn fit in registers (16 KiB / 24 KiB = 64 / 96 VGPRs).
+CIMG_HD bool encode_block_items_ok(int typesize, int filter, int blocksize)
+{
+    return (typesize == 2 || typesize == 4) && filter == FILTER_SHUFFLE && blocksize == 32768;
 }
 
 #ifdef CIMG_EMULATE
@@ -752,6 +760,77 @@ struct EncodeStream {
         }
     }
 
+    // phase A of a block item: ONE pass over the 32 KiB block.  The most significant byte plane goes to LDS (it is encoded
+    // first), the others stay in registers: keep[p][k] holds dword(s) k of plane p as this lane will write them to LDS later.
+    //   typesize 2: unit u = 16 source bytes = 8 bytes of each plane; lane l handles units 64 k + l, k = 0 .. 31
+    //   typesize 4: unit u = 16 source bytes = 4 bytes of each plane
+    CIMG_DEV void load_block_ts2(const uint8_t* src, LV<uint32_t> (&keep)[96])
+    {
+        constexpr int DEPTH = 16;
+        CIMG_UNROLL
+        for (int r = 0; r < 2; r++) {
+            LV<u128> x[DEPTH];
+            CIMG_UNROLL
+            for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { x[k][l] = ld128u(src + 16 * (64 * (DEPTH * r + k) + l)); } }
+            CIMG_UNROLL
+            for (int k = 0; k < DEPTH; k++) {
+                FOR_LANES(l) {
+                    const int u = 64 * (DEPTH * r + k) + l;
+                    uint32_t* d = reinterpret_cast<uint32_t*>(lds + 8 * u);
+                    d[0] = byte_perm(x[k][l].y, x[k][l].x, 0x07050301u);           // plane 1 (high bytes) -> LDS
+                    d[1] = byte_perm(x[k][l].w, x[k][l].z, 0x07050301u);
+                    keep[2 * (DEPTH * r + k)][l] = byte_perm(x[k][l].y, x[k][l].x, 0x06040200u);        // plane 0 -> registers
+                    keep[2 * (DEPTH * r + k) + 1][l] = byte_perm(x[k][l].w, x[k][l].z, 0x06040200u);
+                }
+            }
+        }
+    }
+    CIMG_DEV void load_block_ts4(const uint8_t* src, LV<uint32_t> (&keep)[96])
+    {
+        constexpr int DEPTH = 16;
+        CIMG_UNROLL
+        for (int r = 0; r < 2; r++) {
+            LV<u128> x[DEPTH];
+            CIMG_UNROLL
+            for (int k = 0; k < DEPTH; k++) { FOR_LANES(l) { x[k][l] = ld128u(src + 16 * (64 * (DEPTH * r + k) + l)); } }
+            CIMG_UNROLL
+            for (int k = 0; k < DEPTH; k++) {
+                FOR_LANES(l) {
+                    const int u = 64 * (DEPTH * r + k) + l;
+                    // bytes {0,1} / {2,3} of two elements, then byte s of four elements
+                    const uint32_t lo01 = byte_perm(x[k][l].y, x[k][l].x, 0x05010400u), hi01 = byte_perm(x[k][l].w, x[k][l].z, 0x05010400u);
+                    const uint32_t lo23 = byte_perm(x[k][l].y, x[k][l].x, 0x07030602u), hi23 = byte_perm(x[k][l].w, x[k][l].z, 0x07030602u);
+                    *reinterpret_cast<uint32_t*>(lds + 4 * u) = byte_perm(hi23, lo23, 0x07060302u);              // plane 3 -> LDS
+                    keep[DEPTH * r + k][l] = byte_perm(hi01, lo01, 0x05040100u);                                 // plane 0
+                    keep[32 + DEPTH * r + k][l] = byte_perm(hi01, lo01, 0x07060302u);                            // plane 1
+                    keep[64 + DEPTH * r + k][l] = byte_perm(hi23, lo23, 0x05040100u);                            // plane 2
+                }
+            }
+        }
+    }
+    // a kept plane -> LDS (the wave is done with the plane that was there)
+    CIMG_DEV void restore_plane(const LV<uint32_t> (&keep)[96], int ts, int s)
+    {
+        if (ts == 2) {
+            CIMG_UNROLL
+            for (int k = 0; k < 32; k++) {
+                FOR_LANES(l) {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(lds + 8 * (64 * k + l));
+                    d[0] = keep[2 * k][l];
+                    d[1] = keep[2 * k + 1][l];
+                }
+            }
+        } else {
+            CIMG_UNROLL
+            for (int k = 0; k < 32; k++) {
+                FOR_LANES(l) {
+                    const uint32_t v = s == 0 ? keep[k][l] : (s == 1 ? keep[32 + k][l] : keep[64 + k][l]);
+                    *reinterpret_cast<uint32_t*>(lds + 4 * (64 * k + l)) = v;
+                }
+            }
+        }
+    }
+
     // bitshuffle filter: the first ne8 = ne - ne % 8 elements become 8 * ts bit rows of
     // ne8 / 8 bytes -- row 8 j + k holds bit k of byte j of every element, element i at bit i % 8 of byte i / 8 --
     // and the remaining bytes are copied.  A lane takes one group of 8 elements: 8 * ts contiguous source bytes,
@@ -821,7 +900,7 @@ struct EncodeStream {
         uint32_t* queue;
         {
             const auto a = fresh(ap);
-            items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0);
+            items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0, a->block_items != 0);
             queue = a->queue;
         }
         // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
@@ -838,7 +917,7 @@ struct EncodeStream {
     // block and stream of a work item (encode_items)
     CIMG_DEV static void item_place(kernarg_ptr<EncodeArgs> a, int item, int& b, int& s)
     {
-        if (a->want_split) {
+        if (a->want_split && !a->block_items) {
             const int tb = a->total_blocks;
             b = item % tb;
             s = a->p.streams_per_block - 1 - item / tb;
@@ -847,43 +926,9 @@ struct EncodeStream {
         }
     }
 
-    CIMG_DEV void run_item(int item)
+    // run check + codec on the stream that sits in LDS; leaves payload in the scratch slot and the record in recs
+    CIMG_DEV void encode_resident(int rec_index, int neblock, uint8_t* out, int accel_or_level, uint64_t* dbg, int item)
     {
-        // ---- stage the stream: everything read from the arguments here is dead before the codec loop starts ----------
-        int neblock, accel_or_level;
-        uint8_t* out;
-        uint64_t* dbg;
-        {
-            const auto a = fresh(ap);
-            int b, s;
-            item_place(a, item, b, s);
-            if (b >= a->total_blocks) return;
-            const int chunk = find_chunk(a->descs, a->nchunks, b, a->uniform_nblocks);
-            const ChunkDesc d = uniform_desc(a->descs + chunk);
-            if (d.memcpyed) return;
-            const int j = b - d.blk0;
-            const int ts = a->p.typesize;
-            const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
-            const int bsize = leftover_blk ? d.leftover : d.blocksize;
-            const int ns = (d.split && !leftover_blk) ? ts : 1;
-            if ((ns > 1) != (a->want_split != 0) || s >= ns) return;
-            neblock = bsize / ns;
-            const uint8_t* src = a->raw + d.raw_off + (int64_t)j * d.blocksize;
-            const int filter = a->p.filter;
-            const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
-            out = a->scratch + (int64_t)b * a->p.slot_bytes + (int64_t)s * neblock;
-            accel_or_level = CODEC == CODEC_BLOSCLZ ? a->p.clevel : a->p.accel;
-            dbg = a->dbg;
-#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-            const unsigned long long prof_load0_ = cimg_cycles();
-#endif
-            if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
-            else if (filter == FILTER_BITSHUFFLE) load_block_bitshuffle(src, bsize, ts);
-            else load_block(src, bsize, ts, shuf);
-#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-            if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 14] = cimg_cycles() - prof_load0_;
-#endif
-        }
         const uint8_t* in = lds;
         StreamRec r;
         r.kind = REC_RAW; r.value = 0; r.csize = neblock; r.need = 0;
@@ -902,13 +947,60 @@ struct EncodeStream {
                 wave_copy_l2g(lds, 0, out, neblock);
             }
         }
-        // ---- the record: its address is worked out again from the arguments (nothing of it was kept alive) -------------
+        // the record: its address is worked out again from the arguments (nothing of it was kept alive across the codec loop)
+        StreamRec* dst = fresh(ap)->recs + rec_index;
+        FOR_LANES(l) { if (l == 0) *dst = r; }
+    }
+
+    CIMG_DEV void run_item(int item)
+    {
+        // ---- stage the stream: everything read from the arguments here is dead before the codec loop starts ----------
+        int neblock, accel_or_level, rec_index, planes = 1, ts = 1;
+        uint8_t* out;
+        uint64_t* dbg;
+        LV<uint32_t> keep[96];                 // block items: the byte planes that wait for their turn (dead otherwise)
         {
             const auto a = fresh(ap);
             int b, s;
             item_place(a, item, b, s);
-            StreamRec* dst = a->recs + (int64_t)b * a->p.streams_per_block + s;
-            FOR_LANES(l) { if (l == 0) *dst = r; }
+            if (b >= a->total_blocks) return;
+            const int chunk = find_chunk(a->descs, a->nchunks, b, a->uniform_nblocks);
+            const ChunkDesc d = uniform_desc(a->descs + chunk);
+            if (d.memcpyed) return;
+            const int j = b - d.blk0;
+            ts = a->p.typesize;
+            const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
+            const int bsize = leftover_blk ? d.leftover : d.blocksize;
+            const int ns = (d.split && !leftover_blk) ? ts : 1;
+            if ((ns > 1) != (a->want_split != 0) || s >= ns) return;
+            neblock = bsize / ns;
+            const uint8_t* src = a->raw + d.raw_off + (int64_t)j * d.blocksize;
+            const int filter = a->p.filter;
+            const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
+            const bool whole = ns > 1 && a->block_items != 0;            // host guarantees: typesize 2 or 4, 32 KiB, byte shuffle
+            if (whole) { planes = ns; s = ns - 1; }
+            out = a->scratch + (int64_t)b * a->p.slot_bytes + (int64_t)s * neblock;
+            rec_index = b * a->p.streams_per_block + s;
+            accel_or_level = CODEC == CODEC_BLOSCLZ ? a->p.clevel : a->p.accel;
+            dbg = a->dbg;
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+            const unsigned long long prof_load0_ = cimg_cycles();
+#endif
+            if (whole) { if (ts == 2) load_block_ts2(src, keep); else load_block_ts4(src, keep); }
+            else if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
+            else if (filter == FILTER_BITSHUFFLE) load_block_bitshuffle(src, bsize, ts);
+            else load_block(src, bsize, ts, shuf);
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+            if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 14] = cimg_cycles() - prof_load0_;
+#endif
+        }
+        encode_resident(rec_index, neblock, out, accel_or_level, dbg, item);
+        // block item: the remaining planes, most significant first, each brought from registers into the same LDS
+        for (int s = planes - 2; s >= 0; --s) {
+            restore_plane(keep, ts, s);
+            out -= neblock;
+            rec_index -= 1;
+            encode_resident(rec_index, neblock, out, accel_or_level, dbg, item);
         }
     }
 };

@@ -140,6 +140,7 @@ struct cimg_engine {
     // environment knobs are read ONCE, when the engine is created (diagnostics only; none changes results)
     bool verbose = getenv("CIMG_VERBOSE") != nullptr;
     int enc_wgs_limit = getenv("CIMG_ENC_WGS_PER_CU") ? atoi(getenv("CIMG_ENC_WGS_PER_CU")) : 0;
+    int enc_block_items = getenv("CIMG_ENC_BLOCK_ITEMS") ? atoi(getenv("CIMG_ENC_BLOCK_ITEMS")) : -1;   // -1: by batch size
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
@@ -472,7 +473,16 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;                     // no blocks of that kind in the batch
-        const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0);
+        // Split launch: whole blocks as work items -- each block read from HBM ONCE instead of once per byte plane -- when
+        // the geometry allows it AND the batch is large.  A block item is `typesize` times coarser than a plane item, and
+        // on a small batch the coarser granularity costs more than the second read saves (HBM is a few per cent utilised;
+        // measured on 4 x 4096^2 float16 = 3.2 blocks per resident wave: 537 us against 512 us; from 8 rounds on the tail
+        // is noise).  CIMG_ENC_BLOCK_ITEMS=1 / 0 forces the choice.
+        bool block_items = split && (e->enc_block_items == 1 || (e->enc_block_items < 0 && plan.total_blocks >= 8 * 5 * e->num_cus));
+        if (block_items)
+            for (const ChunkDesc& d : plan.descs)
+                if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
+        const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, block_items);
         uint64_t* dbg = nullptr;
 #ifdef CIMG_PROFILE
         if (e->stamps && split) {       // diagnostic builds: 16 uint64 of cycle accounting per item
@@ -484,7 +494,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
 #endif
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
-                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks};
+                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, block_items ? 1 : 0};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : cimg_encode_streams;
         if ((rc = e->allow_lds(enc_kernel, blz ? 3 : 0, lds_bytes))) return rc;

@@ -18,6 +18,7 @@
 
 namespace cimg { long g_emu_dec_par = 0, g_emu_dec_serial = 0, g_emu_dec_batches = 0; int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
+static int g_emu_block_items = 1;     // tests also run the one-item-per-plane form
 
 extern "C" {
 
@@ -54,7 +55,11 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         if (!lds_bytes) continue;
         std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK);
         uint32_t queue = 0;
-        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks};
+        bool block_items = split && g_emu_block_items;
+        if (block_items)
+            for (const ChunkDesc& d : plan.descs)
+                if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
+        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, block_items ? 1 : 0};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
@@ -68,6 +73,7 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     return 0;
 }
 
+extern "C" void emu_set_block_items(int on) { g_emu_block_items = on; }
 int g_emu_lean = 1;            // tests switch the lean kernel off to cover the general one on every block
 long g_emu_lean_blocks = 0;    // blocks the lean kernel produced since the last emu_stats reset
 extern "C" void emu_set_lean(int on) { g_emu_lean = on; }
