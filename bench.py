@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[2, 4],
                     help="BASELINE.json configuration, counted from 1: 2 = configs[1], 4 x 4096^2 float16 per rank (the headline); "
                          "4 = configs[3], 64 such images over 8 GPUs = 8 images per rank, with the gather of the finished chunks to rank 0")
+    ap.add_argument("--codec", default="lz4", choices=["lz4", "blosclz"], help="not part of the headline (BASELINE configs[1] is lz4)")
     ap.add_argument("--pmc-json", default=None, help="per-launch PMC averages to take roofline.traffic from (profiles/tools/collect.sh)")
     ap.add_argument("--filter", default="shuffle", choices=["shuffle", "bitshuffle", "none"],
                     help="not part of the headline: the reference only uses byte shuffle")
@@ -269,7 +270,7 @@ def main():
 
     eng = hip.Engine(local_rank)
     filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[args.filter]
-    p = hip.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4, filters=(0, 0, 0, 0, 0, filt))
+    p = hip.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4 if args.codec == "lz4" else hip.BLOSCLZ, filters=(0, 0, 0, 0, 0, filt))
 
     def step():
         cb = eng.compress_device(p, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
@@ -359,7 +360,7 @@ def main():
         dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = algo[dom] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         dec_avg_s = ktimes[hip.K_DECODE][0] / max(ktimes[hip.K_DECODE][1], 1) * 1e-3
-        headline = args.family == "tiled" and args.filter == "shuffle"
+        headline = args.family == "tiled" and args.filter == "shuffle" and args.codec == "lz4" and args.config == 2
         traffic, traffic_src = pmc_traffic(hip.KERNELS[dom], args.pmc_json) if headline else (None, None)
         dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE], args.pmc_json) if headline else (None, None)
         out = {
@@ -371,7 +372,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{'BASELINE configs[3] share of one rank: 8 images x ' if args.config == 4 else ''}"
-                                   f"{len(chans)}x{WIDTH}x{HEIGHT} float16 per GPU, lz4 clevel 9 + {FILTER_TEXT[args.filter]}, "
+                                   f"{len(chans)}x{WIDTH}x{HEIGHT} float16 per GPU, {args.codec} clevel 9 + {FILTER_TEXT[args.filter]}, "
                                    f"32 KiB blocks, 4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks, {2 * N // BLOCK} streams), "
                                    f"device-resident, family={args.family}",
                        "element_dtype": "float16", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(C),
@@ -390,7 +391,7 @@ def main():
             "exchange": exchange,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
         }
-        if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle" and args.config == 2:
+        if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle" and args.config == 2 and args.codec == "lz4":
             out["cpu_baseline"] = cpu_baseline(host, budget_s=10.0, policy="all_cores")
             # the reference's own call structure (serial chunks, hw/2 threads inside a chunk for encode, 1 thread decode)
             out["cpu_baseline_reference_policy"] = cpu_baseline(host, budget_s=8.0, policy="reference")

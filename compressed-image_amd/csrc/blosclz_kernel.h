@@ -338,21 +338,23 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
     const int iend = cs + csize, oend = base + n;
     const int clampmax = lds_limit - 1;
     int ip = cs, op = base;
-    uint32_t ctrl;
-    {
-        LV<uint32_t> t;
-        FOR_LANES(l) { t[l] = lds[imin(ip, clampmax)]; }
-        ctrl = readlane(t, 0) & 31u;
-        ip++;
-    }
+    // lane l holds input byte wbase + l.  A literal run (<= 32 bytes + the next control byte) or a match header (<= 4
+    // bytes + the next control byte) that starts in the first 28 bytes of the window is served from these registers, so
+    // most windows feed several tokens: the window is only re-read when the current token starts behind byte 27.
+    LV<uint32_t> w;
+    int wbase = ip;
+    FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
+    uint32_t ctrl = readlane(w, 0) & 31u;
+    ip++;
     for (int guard = 0; guard <= csize + 1; ++guard) {
-        // lane l holds input byte ip + l: a literal run, or a match header, of one token
-        LV<uint32_t> w;
-        FOR_LANES(l) { w[l] = lds[imin(ip + l, clampmax)]; }
+        int k = ip - wbase;
+        if (k > 27) {
+            wbase = ip; k = 0;
+            FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
+        }
         if (ctrl >= 32) {
             int len = (int)(ctrl >> 5) - 1;
             int ofs = (int)(ctrl & 31u) << 8;
-            int k = 0;                                       // bytes of the window consumed
             if (len == 6) {
                 // length bytes: added up to and including the first that is not 255; each needs a byte behind it
                 for (;;) {
@@ -360,31 +362,31 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
                     FOR_LANES(l) { stop[l] = (l >= k) & (w[l] != 255); }
                     const int f = ctz64(ballot(stop));
                     if (f < 64) {
-                        if (ip + f + 1 >= iend) return ERR_DATA;
+                        if (wbase + f + 1 >= iend) return ERR_DATA;
                         len += 255 * (f - k) + (int)readlane(w, f);
                         k = f + 1;
                         break;
                     }
-                    if (ip + 64 >= iend) return ERR_DATA;
+                    if (wbase + 64 >= iend) return ERR_DATA;
                     len += 255 * (64 - k);
-                    ip += 64; k = 0;
-                    FOR_LANES(l) { w[l] = lds[imin(ip + l, clampmax)]; }
+                    wbase += 64; k = 0;
+                    FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
                 }
-                if (k > 56) { ip += k; k = 0; FOR_LANES(l) { w[l] = lds[imin(ip + l, clampmax)]; } }
-            } else if (ip + 1 >= iend) return ERR_DATA;
+                if (k > 56) { wbase += k; k = 0; FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; } }
+            } else if (wbase + k + 1 >= iend) return ERR_DATA;
             const int code = (int)readlane(w, k);
             k++;
             len += 3;
             int ref = op - ofs - code;
             if (code == 255 && ofs == (31 << 8)) {
-                if (ip + k + 1 >= iend) return ERR_DATA;
+                if (wbase + k + 1 >= iend) return ERR_DATA;
                 ofs = ((int)readlane(w, k) << 8) + (int)readlane(w, k + 1);
                 k += 2;
                 ref = op - ofs - BLZ_MAX_DISTANCE;
             }
             if (len > oend - op) return ERR_DATA;
             if (ref - 1 < base) return ERR_DATA;
-            ip += k;
+            ip = wbase + k;
             if (ip >= iend) break;
             ctrl = readlane(w, k);
             ip++;
@@ -406,13 +408,13 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
             }
             op += len;
         } else {
-            const int cnt = (int)ctrl + 1;                   // <= 32: run and the next control byte are in the window
+            const int cnt = (int)ctrl + 1;                   // <= 32: the run and the next control byte are in the window
             if (cnt > oend - op) return ERR_DATA;
             if (ip + cnt > iend) return ERR_DATA;
-            FOR_LANES_W(l) { if (l < cnt) lds[op + l] = (uint8_t)w[l]; }
+            FOR_LANES_W(l) { if (l >= k && l < k + cnt) lds[op + l - k] = (uint8_t)w[l]; }
             op += cnt; ip += cnt;
             if (ip >= iend) break;
-            ctrl = readlane(w, cnt);
+            ctrl = readlane(w, k + cnt);
             ip++;
         }
     }

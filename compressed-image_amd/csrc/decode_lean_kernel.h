@@ -1,5 +1,5 @@
 // decode_lean_kernel.h -- the decode kernel for the blocks that dominate image data: byte-shuffled, split into
-// 2 or 4 byte planes, of which AT MOST ONE is LZ4-coded (the others are stored raw -- noisy low mantissa bytes --
+// 2 or 4 byte planes, of which AT MOST ONE is coded (LZ4 or BloscLZ) (the others are stored raw -- noisy low mantissa bytes --
 // or are run tokens).  Such a block needs LDS only for the one coded plane, so twice as many blocks are resident
 // per CU as in cimg_decode_blocks (which keeps the whole block in LDS), and the serial LZ4 chains -- the thing
 // decode time is made of -- run two per SIMD instead of one.  Raw planes never enter LDS: the un-shuffle merges
@@ -48,11 +48,13 @@ struct DecodeLean {
         const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
         if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || cbytes < HEADER_LEN) return;
         if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) return;
-        if (((b2 >> 28) & 7) != 0 || (flags & (FLAG_MEMCPYED | FLAG_DONT_SPLIT)) || (flags >> 5) != 1) return;
+        const int fmt = flags >> 5;                                           // 0 blosclz, 1 lz4 / lz4hc
+        if (((b2 >> 28) & 7) != 0 || (flags & (FLAG_MEMCPYED | FLAG_DONT_SPLIT)) || (fmt != 0 && fmt != 1)) return;
         if (f0 != 0 || (f1 & 0xFF) != 0 || (int)((f1 >> 8) & 0xFF) != FILTER_SHUFFLE) return;
         if ((ts != 2 && ts != 4) || (bsize & 15) || bsize % ts) return;
         neblock = bsize / ts;
-        if (region_stride(neblock) + 16 > a.lds_bytes) return;
+        const int rs = fmt == 0 ? blz_region_stride(neblock) : region_stride(neblock);
+        if (rs + 16 > a.lds_bytes) return;
         if (cbytes < HEADER_LEN + 4 * d.nblocks) return;
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) return;
@@ -86,7 +88,6 @@ struct DecodeLean {
         const int raw_at = raw0 ? at[0] : at[1];
         const bool want_pre = nwaves == 1 && ts == 2 && neblock == 16384 && (raw0 != raw1);
         if (coded == 1 && wave == lzwave) {
-            const int rs = region_stride(neblock);
             const int park = rs - round16(lz_cs);
             debug_stamp(a.dbg, b, 1);                                             // header walk done
             if (want_pre && lz_cs <= 4096) {
@@ -107,7 +108,8 @@ struct DecodeLean {
                 wave_copy_g2l(c + lz_pos, lds, park, lz_cs);
             }
             debug_stamp(a.dbg, b, 2);                                             // coded bytes staged
-            const int rc = lz4_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes);
+            const int rc = fmt == 0 ? blosclz_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes)
+                                    : lz4_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes);
             // the verdict travels to the other waves through the last LDS word of the allocation
             FOR_LANES_W(l) { *reinterpret_cast<int32_t*>(lds + a.lds_bytes - 4) = rc; }
         }

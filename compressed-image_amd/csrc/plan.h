@@ -202,7 +202,7 @@ inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t
     if (lds > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;
     plan->total_blocks = blk;
     plan->lds_bytes = lds;
-    plan->lds_lean = region_stride(max_bs / 2) + 16;          // decode_lean_kernel.h: the one LZ4-coded plane of a block
+    plan->lds_lean = blz_region_stride(max_bs / 2) + 16;      // decode_lean_kernel.h: the one coded plane of a block (the larger, BloscLZ margin)
     plan->uniform_nblocks = uniform_blocks(plan->descs);
     return 0;
 }

@@ -47,6 +47,7 @@ int main(int argc, char** argv)
 {
     const int rounds = argc > 1 ? atoi(argv[1]) : 300;
     long decoded = 0, rejected = 0;
+    for (int codec : {1, 0})                   // lz4, blosclz
     for (int ts : {1, 2, 4, 8}) {
         for (int filter : {0, 1, 2}) {
             for (int kind = 0; kind < 5; kind++) {
@@ -54,7 +55,7 @@ int main(int argc, char** argv)
                 const int n = blocksize * (int)(1 + rnd(3)) + (int)rnd((uint32_t)blocksize) / ts * ts;
                 std::vector<uint8_t> raw = make_input(kind, n, ts);
                 EmuCParams p{};
-                p.typesize = ts; p.clevel = 9; p.blocksize = blocksize; p.compcode = 1; p.splitmode = 3; p.filters[5] = (uint8_t)filter;
+                p.typesize = ts; p.clevel = 9; p.blocksize = blocksize; p.compcode = codec; p.splitmode = 3; p.filters[5] = (uint8_t)filter;
                 std::vector<uint8_t> comp((size_t)n + 64 + 4096);
                 const int64_t zero = 0;
                 const int32_t nb = n, dest = n + 32;

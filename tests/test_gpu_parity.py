@@ -341,6 +341,26 @@ def test_general_decode_kernel_alone_still_covers_every_block():
         e2.close()
 
 
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_encode_block_items_and_plane_items_give_the_same_bytes(force):
+    """The split encode launch hands out whole blocks (each read from HBM once, waiting planes in registers) on large
+    batches and single byte planes on small ones (CIMG_ENC_BLOCK_ITEMS forces either, read when an engine is created):
+    both must produce the oracle's bytes, for lz4 and blosclz, 2- and 4-byte types, with leftover blocks in the batch."""
+    os.environ["CIMG_ENC_BLOCK_ITEMS"] = force
+    try:
+        e2 = hip.Engine(0)
+    finally:
+        del os.environ["CIMG_ENC_BLOCK_ITEMS"]
+    try:
+        for dtype, arr in ((np.float16, synth.tiled_channel(np.float16, 2048, 256)), (np.float32, synth.tiled_channel(np.float32, 1024, 128)),
+                           (np.uint16, synth.natural_channel(np.uint16, 1024, 100)), (np.float32, synth.natural_channel(np.float32, 1024, 67))):
+            for code in (hip.LZ4, hip.BLOSCLZ):
+                _roundtrip(e2, dtype, arr, 262144, compcode=code)
+                _roundtrip(e2, dtype, arr, 100000 // np.dtype(dtype).itemsize * np.dtype(dtype).itemsize, compcode=code)   # leftover blocks
+    finally:
+        e2.close()
+
+
 def test_lean_and_general_decode_agree_on_mixed_batches(eng):
     """One batch holding chunks the lean kernel takes (tiled float16), chunks it must leave (both planes coded, ragged
     leftover blocks, typesize 1) and a damaged chunk: every good chunk decodes, the damaged one is reported."""
