@@ -555,7 +555,7 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                             w[l].w = f ? fb : alignbyte(q4, q3, sh);
                         }
                         FOR_LANES_W(l) {
-                            const int rem = who[l] < P ? (e0[l] >> 18) - (l & 3) * 16 : 0;
+                            const int rem = who[l] < P ? ((e0[l] >> 18) & 0x7F) - (l & 3) * 16 : 0;
                             uint8_t* d = lds + (e0[l] & 0x3FFFF) + (l & 3) * 16;
                             const uint32_t v[4] = {w[l].x, w[l].y, w[l].z, w[l].w};
                             CIMG_UNROLL
@@ -563,6 +563,7 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                         }
                     }
                 }
+                CIMG_PROF_LAP(7);                               // lane-parallel matches
                 uint64_t todo = tokens & ~parmask;
 #ifdef CIMG_EMULATE
                 g_emu_dec_par += popc64(parmask); g_emu_dec_serial += popc64(todo); g_emu_dec_batches++;

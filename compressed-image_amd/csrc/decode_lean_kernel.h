@@ -10,6 +10,7 @@
 // set -- and cimg_decode_blocks, launched right behind it with the same done[] array, handles (and diagnoses) it.
 #pragma once
 #include "decode_kernel.h"
+#include "decode_pair.h"
 
 namespace cimg {
 
@@ -28,6 +29,10 @@ struct DecodeLean {
     // registers until the un-shuffle (16 KiB = 16 x 16 bytes per lane): its latency hides behind the decode
     LV<u128> pre[16];
     int prefetched = 0;
+    // pair mode (cimg_decode_lean_pair: two waves per block): wave 0 finds the tokens of the LZ4 chain, wave 1 moves the
+    // bytes (decode_pair.h); both carry half of the stored plane in registers
+    int pair_mode = 0, pair_on = 0, mail = 0;
+    Lz4PairProducer prod;
 
     CIMG_DEV DecodeLean(const DecodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
 
@@ -81,12 +86,46 @@ struct DecodeLean {
         ok = 1;
         // which wave runs the serial LZ4 chain (the launch uses ONE wave per block: 9 blocks per CU and the hardware
         // spreads them over the SIMDs; with 4 waves per block 3 of them only wait and the chains clump: 137 vs 125 us)
-        const int lzwave = (int)((((uint32_t)b * 2654435761u) >> 30) & (uint32_t)(nwaves - 1));   // nwaves is 1, 2 or 4
+        const int lzwave = pair_mode ? 0 : (int)((((uint32_t)b * 2654435761u) >> 30) & (uint32_t)(nwaves - 1));   // nwaves is 1, 2 or 4
         // one wave per block (the launch shape): that wave can carry the stored plane through the decode in registers
         // (static indices only: a dynamically indexed member array would push the whole object, pre[] included, to scratch)
         const bool raw0 = kind[0] == 1, raw1 = kind[1] == 1;
         const int raw_at = raw0 ? at[0] : at[1];
         const bool want_pre = nwaves == 1 && ts == 2 && neblock == 16384 && (raw0 != raw1);
+        if (pair_mode) {
+            // two waves per block.  An LZ4 plane is decoded by the pair; anything else by wave 0 alone, as below.
+            mail = (a.lds_bytes - 16 - PAIR_MAIL_BYTES) & ~15;
+            pair_on = coded == 1 && fmt == 1 && rs <= mail;
+            const bool pre2 = ts == 2 && neblock == 16384 && (raw0 != raw1);
+            const int park = rs - round16(lz_cs);
+            if (pair_on && wave == 0) {
+                debug_stamp(a.dbg, b, 1);
+                const int units = lz_cs >> 4;
+                if (pre2 && lz_cs <= 4096) {
+                    LV<u128> t[4];
+                    CIMG_UNROLL
+                    for (int k = 0; k < 4; k++) { FOR_LANES(l) { t[k][l] = ld128u(c + lz_pos + 16 * imin(64 * k + l, imax(units - 1, 0))); } }
+                    LV<uint32_t> tailb;
+                    FOR_LANES(l) { tailb[l] = c[lz_pos + imin((units << 4) + l, lz_cs - 1)]; }
+                    CIMG_UNROLL
+                    for (int k = 0; k < 8; k++) { FOR_LANES(l) { pre[k][l] = ld128u(c + raw_at + 1024 * k + 16 * l); } }
+                    prefetched = 1;
+                    CIMG_UNROLL
+                    for (int k = 0; k < 4; k++) { FOR_LANES(l) { if (64 * k + l < units) st128a(lds + park + 16 * (64 * k + l), t[k][l]); } }
+                    FOR_LANES(l) { if ((units << 4) + l < lz_cs) lds[park + (units << 4) + l] = (uint8_t)tailb[l]; }
+                } else {
+                    wave_copy_g2l(c + lz_pos, lds, park, lz_cs);
+                }
+                debug_stamp(a.dbg, b, 2);
+                prod.init(lds, 0, neblock, park, lz_cs, mail, mail);
+            }
+            if (pair_on && wave == 1 && pre2 && lz_cs <= 4096) {
+                CIMG_UNROLL
+                for (int k = 0; k < 8; k++) { FOR_LANES(l) { pre[k][l] = ld128u(c + raw_at + 1024 * (8 + k) + 16 * l); } }
+                prefetched = 1;
+            }
+            if (pair_on) return;
+        }
         if (coded == 1 && wave == lzwave) {
             const int park = rs - round16(lz_cs);
             debug_stamp(a.dbg, b, 1);                                             // header walk done
@@ -115,6 +154,13 @@ struct DecodeLean {
         }
     }
 
+    // pair mode, wave 0, after the step loop: the chain's verdict goes where the single-wave path leaves it
+    CIMG_DEV void pair_finish()
+    {
+        const int rc = prod.finished ? prod.rc : ERR_FAILURE;        // (the step loop is bounded: it cannot leave a stream half done silently)
+        FOR_LANES_W(l) { *reinterpret_cast<int32_t*>(lds + a.lds_bytes - 4) = rc; }
+    }
+
     // 8 (ts = 2) or 4 (ts = 4) consecutive bytes of plane p, starting at plane offset `off`
     CIMG_DEV uint32_t plane_word(int p, int off) const
     {
@@ -138,10 +184,12 @@ struct DecodeLean {
         }
         if (prefetched) {
             // lane l, piece k: plane bytes [1024 k + 16 l, + 16) of both planes -> 32 contiguous pixels bytes
+            // (pair mode: wave w holds pieces 8 w .. 8 w + 7 in pre[0 .. 7])
             CIMG_UNROLL
             for (int k = 0; k < 16; k++) {
+                if (pair_mode && k >= 8) break;
                 FOR_LANES(l) {
-                    const int off = 1024 * k + 16 * l;
+                    const int off = 1024 * (pair_mode ? 8 * wave + k : k) + 16 * l;
                     const u128 x = ld128a(lds + off);
                     const u128 lo = lz_plane == 0 ? x : pre[k][l], hi = lz_plane == 0 ? pre[k][l] : x;    // plane 0 = low bytes
                     u128 o0, o1;

@@ -994,12 +994,14 @@ struct EncodeStream {
             if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 14] = cimg_cycles() - prof_load0_;
 #endif
         }
-        encode_resident(rec_index, neblock, out, accel_or_level, dbg, item);
-        // block item: the remaining planes, most significant first, each brought from registers into the same LDS
-        for (int s = planes - 2; s >= 0; --s) {
-            restore_plane(keep, ts, s);
-            out -= neblock;
-            rec_index -= 1;
+        // one stream -- or, for a block item, its planes most significant first, each brought from registers into the same
+        // LDS (ONE call site: the codec body is large and must exist once in the kernel)
+        for (int s = planes - 1; s >= 0; --s) {
+            if (s != planes - 1) {
+                restore_plane(keep, ts, s);
+                out -= neblock;
+                rec_index -= 1;
+            }
             encode_resident(rec_index, neblock, out, accel_or_level, dbg, item);
         }
     }

@@ -62,6 +62,44 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_lean(DecodeArgs a)
     if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
 }
 
+// the lean launch with TWO waves per block: wave 0 finds the tokens of the LZ4 chain, wave 1 moves the bytes (decode_pair.h)
+extern "C" __global__ __launch_bounds__(128) void cimg_decode_lean_pair(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    DecodeLean blk(a, lds, (int)blockIdx.x);
+    blk.pair_mode = 1;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
+    blk.phase_a(wave, 2);
+    __syncthreads();
+    if (blk.pair_on) {
+        // both waves reach the barrier of every step; a step consumes input or ends the stream, so csize + 2 steps is a hard bound
+        unsigned long long t_work = 0, t_bar = 0;                   // diagnostics (a.dbg != nullptr only)
+        int steps = 0;
+        for (int step = 0; step <= blk.lz_cs + 2; ++step) {
+            const unsigned long long c0 = a.dbg ? cimg_cycles() : 0;
+            if (wave == 0) blk.prod.compute(step);
+            else lz4_pair_consume(lds, 0, blk.mail + ((step + 1) & 1) * PAIR_SLOT_BYTES, blk.mail);
+            const unsigned long long c1 = a.dbg ? cimg_cycles() : 0;
+            __syncthreads();
+            t_work += c1 - c0; t_bar += (a.dbg ? cimg_cycles() : 0) - c1;
+            ++steps;
+            if (mail_hdr(lds, blk.mail + (step & 1) * PAIR_SLOT_BYTES, 0) == PAIR_END) break;
+        }
+        if (a.dbg && __lane_id() == 0) {
+            uint64_t* d = a.dbg + 16 * (size_t)blockIdx.x + 4 + 4 * wave;      // stamp slots 1 (wave 0) and 2 (wave 1)
+            d[0] = t_work; d[1] = 0; d[2] = t_bar; d[3] = (uint64_t)steps;
+#ifdef CIMG_PAIR_PROF
+            if (wave == 0) { uint64_t* q = a.dbg + 16 * (size_t)blockIdx.x; d[1] = blk.prod.t_parse; q[2] = blk.prod.t_post; q[3] = blk.prod.t_scalar; }
+#endif
+        }
+        if (wave == 0) blk.pair_finish();
+        __syncthreads();
+    }
+    blk.phase_b(wave, 2);
+    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
+}
+
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -144,7 +182,8 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_out;
-    int max_dyn_lds[4] = {0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
+    bool lean_pair = getenv("CIMG_LEAN_PAIR") != nullptr && atoi(getenv("CIMG_LEAN_PAIR")) != 0;   // two waves per lean block (decode_pair.h)
+    int max_dyn_lds[5] = {0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -596,14 +635,19 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     const bool timed = e->timing;
     if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
     if (lean) {
-        DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, dbg,
+        const bool pair = e->lean_pair;
+        const int lean_lds = pair ? plan.lds_lean_pair : plan.lds_lean;
+        DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, lean_lds, dbg,
                       plan.uniform_nblocks, done, e->done_gen, skipped_dev};
         if (e->verbose && !e->lean_batches) {
             int per_cu = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean, e->lean_threads, (size_t)plan.lds_lean);
             fprintf(stderr, "[cimg] lean decode launch: %d bytes LDS, %d threads -> %d workgroups per CU\n", plan.lds_lean, e->lean_threads, per_cu);
         }
-        if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))
+        if (pair) {
+            if (!(rc = e->allow_lds(cimg_decode_lean_pair, 4, lean_lds)))
+                rc = e->launch(CIMG_K_DECODE, cimg_decode_lean_pair, la, plan.total_blocks, 128, lean_lds);
+        } else if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, plan.total_blocks, e->lean_threads, plan.lds_lean);
     }
     // The general kernel goes right behind the lean one -- unless the previous lean batch left it nothing to do: then

@@ -19,10 +19,10 @@ for _ in range(2):
 eng.debug_stamps(True)
 eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_out.ptr, raw_off)
 st = eng.read_stamps(1).astype(np.float64)
-names = ["scalar rest", "batch parse", "chain walk", "scan+literals", "batch matches", "scalar header", "scalar copy", "-"]
+names = ["scalar rest", "batch parse", "chain walk", "scan+literals", "batch matches", "scalar header", "scalar copy", "parallel matches"]
 cyc = st[:, :8].mean(axis=0); cnt = st[:, 8:16].mean(axis=0)
 print(fam, "blocks", len(st), "(last LZ4 stream of each block) total cycles %.0f" % cyc.sum())
-print("   " + "  ".join("%s=%.0f" % (nm, c) for nm, c in zip(names[:7], cyc[:7])))
+print("   " + "  ".join("%s=%.0f" % (nm, c) for nm, c in zip(names[:8], cyc[:8])))
 print("   batch matches %.1f  batches %.1f  scalar-path sequences %.1f (of them longer than 64: %.1f)" % tuple(cnt[:4]))
 if cnt[1] > 0:
     print("   per batch: parse %.0f  walk %.0f  scan+literals %.0f  matches %.0f (%.0f per match)" % (cyc[1] / cnt[1], cyc[2] / cnt[1], cyc[3] / cnt[1], cyc[4] / cnt[1], cyc[4] / max(cnt[0], 1)))
