@@ -985,6 +985,9 @@ struct EncodeStream {
             dbg = a->dbg;
 #if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
             const unsigned long long prof_load0_ = cimg_cycles();
+#elif !defined(CIMG_EMULATE)
+            debug_stamp(dbg, item, 0);                                   // diagnostics (tests/diag_enctimeline.py): item taken
+            if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 4] = (uint64_t)w;
 #endif
             if (whole) { if (ts == 2) load_block_ts2(src, keep); else load_block_ts4(src, keep); }
             else if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
@@ -1004,6 +1007,9 @@ struct EncodeStream {
             }
             encode_resident(rec_index, neblock, out, accel_or_level, dbg, item);
         }
+#if !defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+        debug_stamp(dbg, item, 3);                                       // item done
+#endif
     }
 };
 

@@ -18,23 +18,39 @@
 
 using namespace cimg;
 
+#ifndef CIMG_ENC_GANG_MAX
+#define CIMG_ENC_GANG_MAX 8            // waves per encode workgroup at most (encode_gang)
+#endif
+enum : int { LDS_GRANULE = 1280 };      // bytes; LDS is handed out per workgroup in multiples of this (measured, tests/ubench/launch.hip)
+
 // ====================================================================================================
 //  kernels
 // ====================================================================================================
-extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams(EncodeArgs a)
+// Persistent chains.  A workgroup is a GANG of independent waves: each owns lds_bytes of the workgroup's LDS and runs its own
+// loop over the work queue; they never synchronise.  Why gangs: a CU hands out its 160 KiB of LDS per WORKGROUP in 1280-byte
+// granules (measured, tests/ubench/launch.hip: single-wave workgroups of 32000 B -> 5 per CU, of 32256 .. 32768 B -> 4), so
+// five one-wave workgroups of 32 KiB (plane + byU16 table) do not fit a CU, but ONE five-wave workgroup of exactly 160 KiB does.
+template <int CODEC> CIMG_DEV void encode_gang(uint8_t* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    (void)a;                                   // read through the kernel-argument segment (wave.h: kernarg_ptr)
-    EncodeStream<CODEC_LZ4> es(kernel_args<EncodeArgs>(), lds, (int)blockIdx.x);
+    const auto ap = kernel_args<EncodeArgs>();                   // read through the kernel-argument segment (wave.h: kernarg_ptr)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gang = (int)(blockDim.x >> 6);
+    EncodeStream<CODEC> es(ap, lds + (size_t)wave * (size_t)fresh(ap)->lds_bytes, (int)blockIdx.x * gang + wave);
     es.run();
 }
 
-extern "C" __global__ __launch_bounds__(64) void cimg_encode_streams_blosclz(EncodeArgs a)
+extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode_streams(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     (void)a;
-    EncodeStream<CODEC_BLOSCLZ> es(kernel_args<EncodeArgs>(), lds, (int)blockIdx.x);
-    es.run();
+    encode_gang<CODEC_LZ4>(lds);
+}
+
+extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode_streams_blosclz(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    (void)a;
+    encode_gang<CODEC_BLOSCLZ>(lds);
 }
 
 extern "C" __global__ __launch_bounds__(64) void cimg_layout_chunks(AssembleArgs a)
@@ -164,13 +180,16 @@ struct cimg_engine {
     bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
     // decode: the lean kernel (decode_lean_kernel.h) runs in front of the general one while it pays off
     DevBuf done;                        // uint32 per block: generation stamp of the lean kernel
-    int lean_threads = 64;              // one wave per block (measured best; 64 / 128 / 256 are valid)
+    int lean_threads = getenv("CIMG_LEAN_THREADS") ? atoi(getenv("CIMG_LEAN_THREADS")) : 64;              // one wave per block (measured best; 64 / 128 / 256 are valid)
     uint32_t done_gen = 0;
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
     uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over (1: unknown yet -> general kernel enqueued up front)
     int num_cus = 256;
-    int enc_wgs_per_cu[2] = {0, 0};     // resident encode workgroups per CU for the LDS size in max_dyn_lds-like cache
+    int enc_waves_cu = 1;               // encode waves per CU the registers allow (occupancy query, cached with enc_wgs_lds)
+    int lds_per_cu = 163840, lds_per_wg = 65536;      // device properties
+    int enc_gang = getenv("CIMG_ENC_GANG") ? atoi(getenv("CIMG_ENC_GANG")) : 0;
+    int enc_said_lds = -1, enc_said_gang = -1;
     int enc_wgs_lds[2] = {-1, -1};
     int enc_wgs_codec = -1;
     bool stamps = false;
@@ -364,6 +383,13 @@ int cimg_engine_create(int device, cimg_engine** out)
     cimg_engine* eng = new cimg_engine();
     eng->device = device;
     eng->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.maxSharedMemoryPerMultiProcessor > 0) eng->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    {   // what ONE workgroup may allocate (gfx950: the whole 160 KiB)
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess && v > 0) eng->lds_per_wg = v;
+        else if (prop.sharedMemPerBlock > 0) eng->lds_per_wg = (int)prop.sharedMemPerBlock;
+        if (eng->verbose) fprintf(stderr, "[cimg] LDS: %d bytes per CU, %d per workgroup\n", eng->lds_per_cu, eng->lds_per_wg);
+    }
     e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&eng->s_h2d, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&eng->s_d2h, hipStreamNonBlocking);
@@ -523,34 +549,47 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
         const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, block_items);
         uint64_t* dbg = nullptr;
-#ifdef CIMG_PROFILE
-        if (e->stamps && split) {       // diagnostic builds: 16 uint64 of cycle accounting per item
+        if (e->stamps && split) {       // diagnostics: 16 uint64 per item (start / end stamps; -DCIMG_PROFILE builds: cycle accounting)
             if ((rc = e->reserve(e->dbg, (size_t)items * 128))) return rc;
             if ((rc = e->hip(hipMemsetAsync(e->dbg.p, 0, (size_t)items * 128, e->stream), "dbg memset"))) return rc;
             dbg = (uint64_t*)e->dbg.p;
             e->dbg_count[0] = items;
         }
-#endif
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, block_items ? 1 : 0};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : cimg_encode_streams;
-        if ((rc = e->allow_lds(enc_kernel, blz ? 3 : 0, lds_bytes))) return rc;
-        // persistent workgroups: as many as are resident at once, never more than there are items
+        // persistent chains, as many as are resident at once and never more than there are items; ganged into workgroups so
+        // that the 1280-byte LDS granules of a CU come out even (encode_gang above)
         if (e->enc_wgs_lds[split] != lds_bytes || e->enc_wgs_codec != plan.cp.compcode) {
-            int per_cu = 0;
+            int waves_cu = 0;
             e->enc_wgs_lds[0] = e->enc_wgs_lds[1] = -1;
             e->enc_wgs_codec = plan.cp.compcode;
-            if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, enc_kernel, 64, (size_t)lds_bytes), "occupancy query"))) return rc;
-            e->enc_wgs_per_cu[split] = per_cu > 0 ? per_cu : 1;
+            if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_cu, enc_kernel, 64, 0), "occupancy query"))) return rc;
+            e->enc_waves_cu = waves_cu > 0 ? waves_cu : 1;           // what the registers allow
             e->enc_wgs_lds[split] = lds_bytes;
-            if (e->verbose) fprintf(stderr, "[cimg] encode launch: %d bytes LDS -> %d workgroups per CU x %d CUs\n", lds_bytes, per_cu, e->num_cus);
         }
-        int per_cu_use = e->enc_wgs_per_cu[split];
+        const auto wgs_for = [&](int gang) {                         // resident workgroups per CU for a gang size
+            const int granules = (gang * lds_bytes + LDS_GRANULE - 1) / LDS_GRANULE;
+            return std::min(e->lds_per_cu / LDS_GRANULE / std::max(granules, 1), std::max(e->enc_waves_cu / gang, 0));
+        };
+        int gang = 1;
+        if (e->enc_gang > 0) gang = std::min(e->enc_gang, (int)CIMG_ENC_GANG_MAX);       // diagnostic: forced
+        else if (items > wgs_for(1) * e->num_cus)                    // a small batch spreads single waves over the CUs
+            for (int g = 2; g <= CIMG_ENC_GANG_MAX; ++g)
+                if (g * lds_bytes <= e->lds_per_wg && g * wgs_for(g) > gang * wgs_for(gang)) gang = g;
+        if (gang > 1 && e->allow_lds(enc_kernel, blz ? 3 : 0, gang * lds_bytes)) gang = 1;   // the runtime refused that much LDS for one workgroup
+        if ((rc = e->allow_lds(enc_kernel, blz ? 3 : 0, gang * lds_bytes))) return rc;
+        int per_cu_use = std::max(wgs_for(gang), 1);
         if (e->enc_wgs_limit > 0) per_cu_use = std::max(1, std::min(per_cu_use, e->enc_wgs_limit));   // diagnostic: fewer resident workgroups
-        const int grid = std::min(items, per_cu_use * e->num_cus);
-        if ((rc = e->launch(CIMG_K_ENCODE, enc_kernel, ea, grid, 64, lds_bytes))) return rc;
+        const int grid = std::min((items + gang - 1) / gang, per_cu_use * e->num_cus);
+        if (e->verbose && (e->enc_said_lds != lds_bytes || e->enc_said_gang != gang)) {
+            e->enc_said_lds = lds_bytes; e->enc_said_gang = gang;
+            fprintf(stderr, "[cimg] encode launch: %d bytes LDS per chain, gangs of %d -> %d workgroup(s) per CU = %d chains per CU x %d CUs (grid %d)\n",
+                    lds_bytes, gang, per_cu_use, gang * per_cu_use, e->num_cus, grid);
+        }
+        if ((rc = e->launch(CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes))) return rc;
     }
     AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
                     (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks,
@@ -645,6 +684,12 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
             fprintf(stderr, "[cimg] lean decode launch: %d bytes LDS, %d threads -> %d workgroups per CU\n", plan.lds_lean, e->lean_threads, per_cu);
         }
         if (pair) {
+            if (e->verbose && !e->lean_batches) {
+                int per_cu = 0;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cimg_decode_lean_pair), hipFuncAttributeMaxDynamicSharedMemorySize, lean_lds);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean_pair, 128, (size_t)lean_lds);
+                fprintf(stderr, "[cimg] lean pair decode launch: %d bytes LDS, 128 threads -> %d workgroups per CU\n", lean_lds, per_cu);
+            }
             if (!(rc = e->allow_lds(cimg_decode_lean_pair, 4, lean_lds)))
                 rc = e->launch(CIMG_K_DECODE, cimg_decode_lean_pair, la, plan.total_blocks, 128, lean_lds);
         } else if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))

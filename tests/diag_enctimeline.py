@@ -1,0 +1,47 @@
+# When does every work item of the encode launch start and end, and on which persistent workgroup?  (production build,
+# in-kernel stamps; diagnostics only)
+import sys, os
+sys.path[:0] = [os.path.join(os.getcwd(), "compressed-image_amd"), os.path.join(os.getcwd(), "tests")]
+import numpy as np, faulthandler; faulthandler.dump_traceback_later(90, exit=True)
+from cimg import hip, synth
+fam = sys.argv[1] if len(sys.argv) > 1 else "tiled"
+eng = hip.Engine(0)
+chans = [getattr(synth, fam + "_channel")(np.float16, 4096, 4096, c=c) for c in range(4)]
+host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+n, chunk = host.size, 4 * 1024 * 1024
+nchunks, stride = n // chunk, chunk + 64
+d_raw, d_comp = eng.alloc(n), eng.alloc(nchunks * stride)
+d_raw.upload(host)
+raw_off = np.arange(nchunks) * chunk; comp_off = np.arange(nchunks) * stride
+p = hip.cparams(2)
+for _ in range(3):
+    eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+eng.debug_stamps(True)
+eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+st = eng.read_stamps(0)
+items = len(st)
+t0 = st[:, 1].min()
+start, end = (st[:, 1] - t0) / 100.0, (st[:, 13] - t0) / 100.0
+wg = st[:, 4].astype(np.int64)
+dur = end - start
+half = items // 2
+print(fam, "items", items, "span us %.1f" % end.max(), "workgroups", len(np.unique(wg)))
+for name, sl in (("first half of the queue (high-byte planes)", slice(0, half)), ("second half (low-byte planes)", slice(half, None))):
+    d = dur[sl]
+    print("  %-44s duration us: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f;  starts %.1f..%.1f  ends ..%.1f" % (name, d.mean(), *np.percentile(d, [10, 50, 90]), d.max(), start[sl].min(), start[sl].max(), end[sl].max()))
+# per workgroup: items taken, busy time, last end
+last = np.zeros(wg.max() + 1); busy = np.zeros(wg.max() + 1); cnt = np.zeros(wg.max() + 1, dtype=int); hi = np.zeros(wg.max() + 1, dtype=int)
+np.maximum.at(last, wg, end); np.add.at(busy, wg, dur); np.add.at(cnt, wg, 1); np.add.at(hi, wg[:half], 1)
+print("  per workgroup: items mean %.2f; high-byte planes taken histogram %s" % (cnt.mean(), np.bincount(hi).tolist()))
+print("  last end per workgroup us: p0 %.1f p10 %.1f p50 %.1f p90 %.1f p100 %.1f;  busy fraction of span mean %.3f" % (*np.percentile(last, [0, 10, 50, 90, 100]), (busy / end.max()).mean()))
+print("  sum of item time / (workgroups x span) = %.3f   ideal span (perfect balance) %.1f us" % (dur.sum() / (len(last) * end.max()), dur.sum() / len(last)))
+# does sharing a SIMD matter?  HW_ID simd [5:4], cu [11:8], sh [12], se [15:13]
+hw = st[:, 2].astype(np.int64); xcc = st[:, 3].astype(np.int64) & 15
+simd_key = (xcc * 4096 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)) * 4 + ((hw >> 4) & 3)
+wg_simd = np.zeros(wg.max() + 1, dtype=np.int64); wg_simd[wg] = simd_key
+_, inv, per_simd = np.unique(wg_simd, return_inverse=True, return_counts=True)
+share = per_simd[inv]                       # waves on the SIMD of each workgroup
+for k in np.unique(share):
+    m = share[wg[:half]] == k
+    print("  high-byte plane duration on a SIMD holding %d encode wave(s): mean %.1f us (%d items)" % (k, dur[:half][m].mean(), m.sum()))
+os._exit(0)

@@ -28,3 +28,13 @@ lz_end = None
 for name, d in (("total", end - start), ("header walk", s0 - start), ("stage coded bytes", s1 - s0), ("LZ4 + unshuffle", end - s1)):
     print("   %-34s mean %.1f p50 %.1f p90 %.1f max %.1f us" % (name, d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 print("   avg concurrent WGs per CU %.2f" % ((end - start).sum() / end.max() / 256))
+# where did the workgroups run?  HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]
+hw = st[:, 2].astype(np.int64); xcc = st[:, 3].astype(np.int64) & 15
+cu_key = xcc * 4096 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)
+simd = (hw >> 4) & 3
+early = start < 2.0
+keys, cnt = np.unique(cu_key[early], return_counts=True)
+print("   CUs seen %d (early %d); early workgroups per CU: min %d median %d max %d; histogram %s" % (len(np.unique(cu_key)), len(keys), cnt.min(), np.median(cnt), cnt.max(), np.bincount(cnt).tolist()))
+print("   early by xcc:", np.bincount(xcc[early], minlength=8).tolist(), " all by xcc:", np.bincount(xcc, minlength=8).tolist(), " early wave-0 by simd:", np.bincount(simd[early], minlength=4).tolist())
+hist, edges = np.histogram(start, bins=[0, 1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128])
+print("   start histogram (us bins", edges.tolist(), "):", hist.tolist())
