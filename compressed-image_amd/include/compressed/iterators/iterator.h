@@ -3,13 +3,26 @@
 // recompresses it and stores it back.  Same contract as the reference (compressed/iterators/iterator.h:
 // operator* :97-141, destructor :72-93, ++ :143-156), including that a visited chunk is always written
 // back.  What differs is the granularity of the engine calls: the reference decodes and re-encodes one chunk at
-// a time; here the iterator works on a WINDOW of up to 8 chunks -- one batched decode when the window is entered
+// a time; here the iterator works on a WINDOW of up to 8 chunks (a quarter of the channel if that is less) -- one batched decode when the window is entered
 // (into a recycled page-locked buffer), one batched encode of the visited chunks when it is left or the iterator
 // dies.  A visited chunk therefore reaches the channel when its window is flushed, not at ++; code that reads a
 // chunk back through the channel while still iterating over the same window sees the old bytes.
+//
+// The windows are DOUBLE-BUFFERED (the reference's decode -> modify -> encode ping-pong is strictly
+// serial per channel, iterator.h:118-126).  Entering window k hands the window just left to a helper task that
+// (1) recompresses it and stores its chunks, then (2) decodes window k + 1 into a second page-locked buffer -- both
+// while the caller's loop body works on window k.  The next window switch only waits for that task.  The engine calls
+// are the same batched ones (one encode, one decode per window); they are serialised by the engine's own lock, so
+// several iterators (ranges::zip over three channels) interleave their windows on one device.  Consequences, beyond
+// the window rule above: chunks of window k + 1 are read up to one window early, so writing them through the channel
+// (set_chunk) while an iterator is about to enter them is not seen by that iterator; an exception of the helper
+// task (a codec error) surfaces at the next window switch or is swallowed by the destructor, like the reference's
+// destructor does (iterator.h:72-93).
 #pragma once
 #include <cstddef>
+#include <cstdlib>
 #include <algorithm>
+#include <future>
 #include <iterator>
 #include <memory>
 #include <span>
@@ -53,32 +66,27 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		{
 			if (this != &other)
 			{
-				flush();
+				finish();
 				m_Schunk = other.m_Schunk; m_Cctx = other.m_Cctx; m_Dctx = other.m_Dctx;
 				m_Index = other.m_Index; m_Width = other.m_Width; m_Height = other.m_Height;
-				m_WinFirst = npos;
 			}
 			return *this;
 		}
 
 		~channel_iterator()
 		{
-			try { flush(); } catch (...) {}
+			try { finish(); } catch (...) {}
 		}
 
 		value_type operator*()
 		{
 			if (!m_Schunk || !m_Cctx || !m_Dctx || m_Index >= num_chunks())
 				throw std::runtime_error("Invalid Iterator struct encountered, cannot dereference item");
-			if (m_WinFirst == npos || m_Index < m_WinFirst || m_Index >= m_WinFirst + m_WinElems.size())
-			{
-				flush();                                   // recompress what the previous window handed out
-				load_window(m_Index);
-			}
-			const size_t k = m_Index - m_WinFirst;
-			m_Visited[k] = true;
-			T* px = reinterpret_cast<T*>(m_Buffer.get()) + m_WinOffset[k];
-			return value_type(std::span<T>(px, m_WinElems[k]), m_Width, m_Height, m_Index, chunk_bytes());
+			if (!m_Cur.holds(m_Index)) enter(m_Index);
+			const size_t k = m_Index - m_Cur.first;
+			m_Cur.visited[k] = true;
+			T* px = reinterpret_cast<T*>(m_Cur.buffer.get()) + m_Cur.offset[k];
+			return value_type(std::span<T>(px, m_Cur.elems[k]), m_Width, m_Height, m_Index, chunk_bytes());
 		}
 
 		channel_iterator& operator++()
@@ -110,54 +118,127 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		size_t m_Index = 0;
 		size_t m_Width = 0;
 		size_t m_Height = 0;
-		static constexpr size_t s_window_chunks = 8;
-		size_t m_WinFirst = npos;                 // first chunk of the decoded window (npos: none)
-		std::vector<size_t> m_WinOffset, m_WinElems;   // element offset / count of each window chunk inside m_Buffer
-		std::vector<bool> m_Visited;              // handed out since the window was loaded -> written back on flush
-		std::shared_ptr<std::byte> m_Buffer;      // the window's pixels (recycled page-locked memory)
+		// chunks per window: up to 8 (32 MiB of pixels at the default chunk size -- enough to fill the device), but at least four
+		// windows per channel so that the helper task has something to overlap with
+		static constexpr size_t s_max_window_chunks = 8;
+		static size_t window_chunks(size_t total_chunks) noexcept { return std::clamp<size_t>((total_chunks + 3) / 4, 1, s_max_window_chunks); }
+
+		// a decoded run of chunks [first, first + elems.size()) in one page-locked buffer
+		struct window
+		{
+			size_t first = npos;
+			std::vector<size_t> offset, elems;        // element offset / count of each chunk inside buffer
+			std::vector<bool> visited;                // handed out since the window was loaded -> written back on flush
+			std::shared_ptr<std::byte> buffer;        // recycled page-locked memory
+			bool holds(size_t index) const noexcept { return first != npos && index >= first && index < first + elems.size(); }
+			bool overlaps(size_t lo, size_t hi) const noexcept { return first != npos && lo < first + elems.size() && first < hi; }
+			void drop() { first = npos; offset.clear(); elems.clear(); visited.clear(); buffer.reset(); }
+		};
+		window m_Cur;                                  // the window the caller is working on
+		std::shared_ptr<window> m_Ahead;               // filled by the helper task: the window after m_Cur
+		std::future<void> m_Task;                      // write-back of the previous window, then the read-ahead
 
 		size_t num_chunks() const { return m_Schunk ? std::visit([](auto& s) { return s.num_chunks(); }, *m_Schunk) : 0; }
 
-		// decode chunks [first, first + s_window_chunks) with ONE engine call
-		void load_window(size_t first)
+		// decode chunks [first, first + window_chunks) with ONE engine call
+		static void load_window(blosc2::schunk_var<T>& schunk, window& w, size_t first)
 		{
-			const size_t count = std::min(s_window_chunks, num_chunks() - first);
-			m_WinOffset.assign(count, 0);
-			m_WinElems.assign(count, 0);
-			m_Visited.assign(count, false);
+			const size_t total_chunks = std::visit([](auto& s) { return s.num_chunks(); }, schunk);
+			const size_t count = std::min(window_chunks(total_chunks), total_chunks - first);
+			w.offset.assign(count, 0);
+			w.elems.assign(count, 0);
+			w.visited.assign(count, false);
 			size_t total = 0;
 			for (size_t k = 0; k < count; ++k)
 			{
-				m_WinOffset[k] = total;
-				m_WinElems[k] = std::visit([&](auto& s) { return s.chunk_elements(first + k); }, *m_Schunk);
-				total += m_WinElems[k];
+				w.offset[k] = total;
+				w.elems[k] = std::visit([&](auto& s) { return s.chunk_elements(first + k); }, schunk);
+				total += w.elems[k];
 			}
-			m_Buffer = detail::pinned_pool::get().arena(std::max<size_t>(total * sizeof(T), 1));
+			w.buffer = detail::pinned_pool::get().arena(std::max<size_t>(total * sizeof(T), 1));
 			std::vector<blosc2::batch::target> work;
-			std::visit([&](auto& s) { s.plan_decode_range(reinterpret_cast<T*>(m_Buffer.get()), first, count, work); }, *m_Schunk);
+			std::visit([&](auto& s) { s.plan_decode_range(reinterpret_cast<T*>(w.buffer.get()), first, count, work); }, schunk);
 			blosc2::batch::decompress(work);
-			m_WinFirst = first;
+			w.first = first;
 		}
 
-		// write the visited chunks of the window back, compressed with ONE engine call
-		void flush()
+		// write the visited chunks of a window back, compressed with ONE engine call
+		static void store_window(blosc2::schunk_var<T>& schunk, blosc2::context_raw_ptr cctx, window& w)
 		{
-			if (m_WinFirst == npos || !m_Schunk) return;
+			if (w.first == npos) return;
 			std::vector<blosc2::batch::piece> pieces;
 			std::vector<size_t> where;
-			for (size_t k = 0; k < m_Visited.size(); ++k)
-				if (m_Visited[k])
+			for (size_t k = 0; k < w.visited.size(); ++k)
+				if (w.visited[k])
 				{
-					pieces.push_back({ m_Buffer.get() + m_WinOffset[k] * sizeof(T), m_WinElems[k] * sizeof(T) });
-					where.push_back(m_WinFirst + k);
+					pieces.push_back({ w.buffer.get() + w.offset[k] * sizeof(T), w.elems[k] * sizeof(T) });
+					where.push_back(w.first + k);
 				}
-			const size_t first = m_WinFirst;
-			m_WinFirst = npos;
-			(void)first;
+			w.first = npos;
 			if (pieces.empty()) return;
-			auto chunks = blosc2::batch::compress(m_Cctx, pieces, chunk_bytes());
+			const size_t nominal = std::visit([](auto& s) { return s.chunk_bytes(); }, schunk);
+			auto chunks = blosc2::batch::compress(cctx, pieces, nominal);
 			for (size_t i = 0; i < chunks.size(); ++i)
-				std::visit([&](auto& s) { s.set_chunk(std::move(chunks[i]), where[i]); }, *m_Schunk);
+				std::visit([&](auto& s) { s.set_chunk(std::move(chunks[i]), where[i]); }, schunk);
+		}
+
+		static bool serial()
+		{
+			static const bool on = [] { const char* v = std::getenv("CIMG_ITERATOR_SERIAL"); return v && *v && *v != '0'; }();
+			return on;
+		}
+
+		// wait for the helper task; its exception (if any) is rethrown here
+		void wait()
+		{
+			if (m_Task.valid()) m_Task.get();
+		}
+
+		// The caller moves on to the window that starts at (or holds) `index`: take the read-ahead if it is the right one,
+		// else decode now; then hand the window just left to the helper task, which also reads the next one ahead.
+		void enter(size_t index)
+		{
+			wait();
+			window left = std::move(m_Cur);
+			m_Cur.drop();
+			if (m_Ahead && m_Ahead->holds(index)) m_Cur = std::move(*m_Ahead);
+			else
+			{
+				// not the sequential case (first dereference, or the iterator was moved by hand): a window that shares
+				// chunks with the one just left must see them written back first
+				if (left.overlaps(index, index + s_max_window_chunks)) store_window(*m_Schunk, m_Cctx, left);
+				load_window(*m_Schunk, m_Cur, index);
+			}
+			m_Ahead.reset();
+			if (serial())                                  // diagnostics (CIMG_ITERATOR_SERIAL=1): no helper task, the reference's order
+			{
+				store_window(*m_Schunk, m_Cctx, left);
+				return;
+			}
+			const size_t next = m_Cur.first + m_Cur.elems.size();
+			const bool ahead = next < num_chunks();
+			if (left.first == npos && !ahead) return;
+			auto target = ahead ? std::make_shared<window>() : std::shared_ptr<window>();
+			m_Ahead = target;
+			m_Task = std::async(std::launch::async,
+				[schunk = m_Schunk, cctx = m_Cctx, left = std::move(left), target, next]() mutable
+				{
+					store_window(*schunk, cctx, left);
+					left.drop();
+					if (target) load_window(*schunk, *target, next);
+				});
+		}
+
+		// everything handed out so far reaches the channel; nothing stays in flight
+		void finish()
+		{
+			if (!m_Schunk) { m_Cur.drop(); m_Ahead.reset(); return; }
+			std::exception_ptr err;
+			try { wait(); } catch (...) { err = std::current_exception(); }
+			m_Ahead.reset();
+			try { store_window(*m_Schunk, m_Cctx, m_Cur); } catch (...) { if (!err) err = std::current_exception(); }
+			m_Cur.drop();
+			if (err) std::rethrow_exception(err);
 		}
 	};
 }

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <numeric>
 #include <string>
@@ -132,6 +133,71 @@ static void channel_cases()
 		for (auto it = z.begin(); it != z.end(); ++it) { auto ch = *it; if (it.chunk_index() == 3 || it.chunk_index() == 12) for (auto& px : ch) px = 77; }
 		all = z.get_decompressed();
 		for (size_t i = 0; i < all.size(); ++i) CHECK(all[i] == ((i / (w * 4) == 3 || i / (w * 4) == 12) ? 77 : 9));
+	}
+	// double-buffered windows (iterator.h: write-back of window k-1 and read-ahead of window k+1 run behind the loop body):
+	// (a) dereferences that skip windows -- the read-ahead is not the window wanted -- and a pass that touches one chunk in
+	// three; (b) three channels in lock step through ranges::zip, 21 chunks each; (c) the chunks an iterator pass leaves
+	// behind are byte-identical to compressing the same pixels directly, and (CIMG_TEST_DUMP) are written out so that
+	// tests/test_host_mirror.py can hold them against the oracle
+	{
+		const size_t w = 32, h = 84, chunk = 32 * 4 * sizeof(uint16_t), per = w * 4;    // 21 chunks of 128 pixels
+		std::vector<uint16_t> d(w * h);
+		for (size_t i = 0; i < d.size(); ++i) d[i] = static_cast<uint16_t>((i / 5) * 3);
+		channel<uint16_t> c(std::span<const uint16_t>(d), w, h, enums::codec::lz4, 9, 128, chunk);
+		std::vector<uint16_t> want = d;
+		{
+			auto it = c.begin();
+			{ auto ch = *it; for (auto& px : ch) px = 11; }                                  // chunk 0 (window 0..7, read-ahead 8..15)
+			for (int k = 0; k < 17; ++k) ++it;
+			{ auto ch = *it; CHECK(it.chunk_index() == 17); for (auto& px : ch) px = 17; }   // window 17..20: not the read-ahead
+			++it; ++it;
+			{ auto ch = *it; CHECK(ch.size() == per); for (auto& px : ch) px = static_cast<uint16_t>(px + 1); }   // chunk 19, same window
+		}
+		for (size_t i = 0; i < per; ++i) { want[i] = 11; want[17 * per + i] = 17; want[19 * per + i] = static_cast<uint16_t>(want[19 * per + i] + 1); }
+		CHECK(c.get_decompressed() == want);
+		for (auto it = c.begin(); it != c.end(); ++it)
+			if (it.chunk_index() % 3 == 1) { auto ch = *it; for (auto& px : ch) px = static_cast<uint16_t>(px ^ 0x5555); }
+		for (size_t i = 0; i < want.size(); ++i) if ((i / per) % 3 == 1) want[i] = static_cast<uint16_t>(want[i] ^ 0x5555);
+		CHECK(c.get_decompressed() == want);
+
+		channel<uint16_t> r(std::span<const uint16_t>(d), w, h, enums::codec::lz4, 9, 128, chunk), g(std::span<const uint16_t>(d), w, h, enums::codec::blosclz, 9, 128, chunk),
+			b(std::span<const uint16_t>(d), w, h, enums::codec::lz4, 5, 128, chunk);
+		size_t visited = 0;
+		for (auto [cr, cg, cb] : ranges::zip(r, g, b))
+		{
+			for (auto [pr, pg, pb] : ranges::zip(cr, cg, cb)) { CHECK(pr == pg && pg == pb); pr = static_cast<uint16_t>(pr + 1); pg = static_cast<uint16_t>(pg + 2); pb = static_cast<uint16_t>(pr + pg); }
+			++visited;
+		}
+		CHECK(visited == 21);
+		auto dr = r.get_decompressed(), dg = g.get_decompressed(), db = b.get_decompressed();
+		bool ok = true;
+		for (size_t i = 0; i < d.size(); ++i) ok = ok && dr[i] == static_cast<uint16_t>(d[i] + 1) && dg[i] == static_cast<uint16_t>(d[i] + 2) && db[i] == static_cast<uint16_t>(2 * d[i] + 3);
+		CHECK(ok);
+
+		// (c) bytes: iterator pass vs direct compression of the same pixels
+		channel<uint16_t> direct(std::span<const uint16_t>(dr), w, h, enums::codec::lz4, 9, 128, chunk);
+		auto raw_it = std::visit([](auto& s) { return s.to_schunk(); }, r.chunks());
+		auto raw_direct = std::visit([](auto& s) { return s.to_schunk(); }, direct.chunks());
+		CHECK(raw_it->nchunks == 21 && raw_direct->nchunks == 21);
+		auto csize = [](const uint8_t* ch) { return static_cast<size_t>(ch[12]) | (static_cast<size_t>(ch[13]) << 8) | (static_cast<size_t>(ch[14]) << 16) | (static_cast<size_t>(ch[15]) << 24); };
+		bool same = true;
+		for (int64_t k = 0; k < 21 && raw_it->nchunks == 21 && raw_direct->nchunks == 21; ++k)
+			same = same && csize(raw_it->data[k]) == csize(raw_direct->data[k]) && std::equal(raw_it->data[k], raw_it->data[k] + csize(raw_it->data[k]), raw_direct->data[k]);
+		CHECK(same);
+		if (const char* path = std::getenv("CIMG_TEST_DUMP"))
+			if (FILE* f = std::fopen(path, "wb"))
+			{
+				const uint32_t hdr[6] = { 2, 128, static_cast<uint32_t>(chunk), 21, static_cast<uint32_t>(w), static_cast<uint32_t>(h) };   // typesize, blocksize, chunk bytes, chunks
+				std::fwrite(hdr, sizeof(hdr), 1, f);
+				std::fwrite(dr.data(), sizeof(uint16_t), dr.size(), f);
+				for (int64_t k = 0; k < raw_it->nchunks; ++k)
+				{
+					const uint32_t n = static_cast<uint32_t>(csize(raw_it->data[k]));
+					std::fwrite(&n, 4, 1, f);
+					std::fwrite(raw_it->data[k], 1, n, f);
+				}
+				std::fclose(f);
+			}
 	}
 	// lazy factories (python test_channel.py:71-190 through the C++ surface)
 	{
