@@ -212,6 +212,58 @@ CIMG_DEV bool emit_pending(const uint8_t* in, cimg_global_u8p out, int cap, int&
     return true;
 }
 
+// Is there ANY match in the plane?  (No, for the low mantissa bytes of an image.)  The probes of LZ4's first search sit at
+// positions that do not depend on the data for as long as nothing is found, so that search is walked here window by
+// window with the bare minimum -- slots read, written, read back, one candidate compare -- and without any of the
+// sequence state of lz4_encode_body being alive.  Two probes of a window that share a slot are settled in place (the later
+// one owns the slot and has the earlier one as its candidate); three or more, or any candidate that compares equal, end
+// the walk with "maybe": the caller clears the table again and runs the full encoder, which costs a compressible plane one
+// wasted window.  Returns true when the search reached the end of the plane without a match: the block is its literals.
+CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n, int s64, int f64, int mflimit_p1)
+{
+    for (int t0 = 0; t0 <= n; t0 += 64) {                               // hard bound: a window commits 64 probes
+        LV<int> pos;
+        LV<bool> inside;
+        FOR_LANES(l) {
+            const int t = t0 + l;
+            int p = 1 + t, gap = 1;                                      // the search starts at position 1
+            if (t > 0) { p = 2 + skip_prefix(s64 + t - 1) - f64; gap = (s64 + t - 1) >> 6; }
+            pos[l] = p;
+            inside[l] = p + gap <= mflimit_p1;
+        }
+        const uint64_t in_mask = ballot(inside);                         // a prefix of the lanes
+        if (!in_mask) return true;
+        LV<uint32_t> v, h, old, rb, cv;
+        LV<bool> lost, equal;
+        FOR_LANES(l) { v[l] = lds_ld32u(in, inside[l] ? pos[l] : 0); h[l] = lz4_hash(v[l]); }
+        FOR_LANES(l) { old[l] = tab16[h[l]]; }
+        FOR_LANES_W(l) { if (inside[l]) tab16[h[l]] = (uint16_t)pos[l]; }
+        FOR_LANES(l) { rb[l] = tab16[h[l]]; cv[l] = lds_ld32u(in, (int)old[l]); }
+        FOR_LANES(l) {
+            lost[l] = inside[l] & (rb[l] != (uint32_t)(uint16_t)pos[l]);
+            equal[l] = inside[l] & (cv[l] == v[l]);
+        }
+        if (ballot(equal)) return false;
+        if (ballot(lost)) {
+            // the lanes that lost their slot write again: one loser per slot means pairs, and its second read-back is its own
+            LV<uint32_t> rb2, wv;
+            LV<bool> crowd, same;
+            FOR_LANES_W(l) { if (lost[l]) tab16[h[l]] = (uint16_t)pos[l]; }
+            FOR_LANES(l) { rb2[l] = tab16[h[l]]; wv[l] = lds_ld32u(in, (int)rb[l]); }
+            FOR_LANES(l) {
+                crowd[l] = lost[l] & (rb2[l] != (uint32_t)(uint16_t)pos[l]);
+                same[l] = lost[l] & (wv[l] == v[l]);                     // the other probe of the pair has the same four bytes
+            }
+            if (ballot(crowd) | ballot(same)) return false;
+            // the later probe of each pair owns the slot
+            FOR_LANES_W(l) { if (inside[l] && rb2[l] != (uint32_t)(uint16_t)pos[l] && (uint32_t)pos[l] > rb2[l]) tab16[h[l]] = (uint16_t)pos[l]; }
+        }
+        CIMG_STAT(g_emu_windows);
+        if (~in_mask) return true;                                       // the window that saw the end of the plane
+    }
+    return false;
+}
+
 // Bit-exact LZ4_compress_fast(in, out, n, cap, accel) in limited-output mode, byU16 table, by one wave.
 // in: LDS plane (8 readable bytes past the end), tab: 16 KiB LDS.  Returns bytes written, 0 if the
 // result does not fit cap.  need_out = smallest cap that still succeeds.
@@ -239,7 +291,18 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
     int np = 0;
     FOR_LANES(l) { P_anchor[l] = 0; P_lit[l] = 0; P_off[l] = 0; P_mcode[l] = 0; }
 
-    if (n >= 13) {
+    bool hopeless = false;
+    if (n >= 13 + 64) {
+        hopeless = lz4_no_match_at_all(in, tab16, n, s64, f64, mflimit_p1);
+        if (hopeless) anchor = 0;
+        else {
+            const u128 z = {0, 0, 0, 0};
+            for (int u0 = 0; u0 < LZ4_HASH_BYTES / 16; u0 += 64) {
+                FOR_LANES(l) { st128a(tab + 16 * (u0 + l), z); }
+            }
+        }
+    }
+    if (n >= 13 && !hopeless) {
         {   // first byte
             LV<uint32_t> v0;
             FOR_LANES(l) { v0[l] = lds_ld32u(in, 0); }
