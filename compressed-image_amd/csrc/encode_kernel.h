@@ -1049,7 +1049,7 @@ struct EncodeStream {
 #if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
             const unsigned long long prof_load0_ = cimg_cycles();
 #elif !defined(CIMG_EMULATE)
-            debug_stamp(dbg, item, 0);                                   // diagnostics (tests/diag_enctimeline.py): item taken
+            debug_stamp(dbg, item, 0);                                   // diagnostics (tools/diag_enctimeline.py): item taken
             if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 4] = (uint64_t)w;
 #endif
             if (whole) { if (ts == 2) load_block_ts2(src, keep); else load_block_ts4(src, keep); }

@@ -2,7 +2,7 @@
 //
 // Everything the host mirror allocates as the *destination of a device-to-host copy* comes from here: the arena
 // a batch of compressed chunks lives in, and the pixel buffers the Python binding returns.  Two measured reasons
-// (tests/diag_pymodule2.py): a page-locked destination is filled by DMA at PCIe speed, and a recycled buffer has
+// (tools/diag_pymodule2.py): a page-locked destination is filled by DMA at PCIe speed, and a recycled buffer has
 // no first-touch page faults -- decoding 64 MiB into a fresh numpy array took 22 ms, into a recycled page-locked
 // buffer 3.6 ms.  Live page-locked memory is budgeted (CIMG_PINNED_LIMIT_MB, default 8192); past the budget the
 // pool hands out ordinary memory, which is slower but always works.
