@@ -575,7 +575,10 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             return std::min(e->lds_per_cu / LDS_GRANULE / std::max(granules, 1), std::max(e->enc_waves_cu / gang, 0));
         };
         int gang = 1;
-        if (e->enc_gang > 0) gang = std::min(e->enc_gang, (int)CIMG_ENC_GANG_MAX);       // diagnostic: forced
+        if (e->enc_gang > 0) {                                       // diagnostic: forced, as far as one workgroup's LDS goes
+            gang = std::min(e->enc_gang, (int)CIMG_ENC_GANG_MAX);
+            while (gang > 1 && (gang * lds_bytes > e->lds_per_wg || wgs_for(gang) < 1)) --gang;
+        }
         else if (items > wgs_for(1) * e->num_cus)                    // a small batch spreads single waves over the CUs
             for (int g = 2; g <= CIMG_ENC_GANG_MAX; ++g)
                 if (g * lds_bytes <= e->lds_per_wg && g * wgs_for(g) > gang * wgs_for(gang)) gang = g;

@@ -361,6 +361,43 @@ def test_encode_block_items_and_plane_items_give_the_same_bytes(force):
         e2.close()
 
 
+@pytest.mark.parametrize("gang", ["1", "3", "5", "8"])
+def test_encode_gangs_give_the_same_bytes(gang):
+    """The encode launch packs independent chains into workgroups of 1..8 waves so that the CU's LDS granules come out even
+    (engine.hip: encode_gang; five 32 KiB chains only fit a CU as ONE 160 KiB workgroup).  CIMG_ENC_GANG forces the size,
+    read when an engine is created; a batch large enough to take the automatic choice runs as well.  Same bytes as the
+    oracle every way, for lz4 and blosclz, split and unsplit blocks, with a leftover block in the batch."""
+    os.environ["CIMG_ENC_GANG"] = gang
+    try:
+        e2 = hip.Engine(0)
+    finally:
+        del os.environ["CIMG_ENC_GANG"]
+    try:
+        for dtype, arr in ((np.float16, synth.tiled_channel(np.float16, 2048, 256)), (np.float32, synth.natural_channel(np.float32, 1024, 67)),
+                           (np.uint8, synth.tiled_channel(np.uint8, 1024, 200))):
+            for code in (hip.LZ4, hip.BLOSCLZ):
+                _roundtrip(e2, dtype, arr, 262144, compcode=code)
+                _roundtrip(e2, dtype, arr, 100000 // np.dtype(dtype).itemsize * np.dtype(dtype).itemsize, compcode=code)
+    finally:
+        e2.close()
+
+
+def test_encode_automatic_gang_on_a_batch_that_fills_the_device(eng):
+    """1536 blocks x 2 planes is more work items than single-wave workgroups fit the device (4 per CU at 32 KiB): the engine
+    switches to gangs of five on its own.  Oracle bytes on a sample of the chunks, pixels on all of them."""
+    a = synth.tiled_channel(np.float16, 4096, 6144)                     # 48 MiB = 12 chunks of 4 MiB = 1536 blocks
+    chunk = 4 * 1024 * 1024
+    sizes = [chunk] * (a.nbytes // chunk)
+    chunks = eng.compress_host(hip.cparams(2), a, sizes, [chunk + 32] * len(sizes))
+    raw = a.view(np.uint8).ravel()
+    for k in (0, 5, len(sizes) - 1):
+        rc, want = O.compress(O.cparams(2), raw[k * chunk:(k + 1) * chunk])
+        assert rc == len(chunks[k]) and want == bytes(chunks[k])
+    outs, status = eng.decompress_host(chunks)
+    assert not status.any()
+    assert np.array_equal(np.concatenate(outs), raw)
+
+
 def test_two_wave_lean_decode_gives_the_same_pixels():
     """CIMG_LEAN_PAIR=1 (read when an engine is created): the lean decode launch with two waves per block -- wave 0 finds
     the tokens of the LZ4 chain, wave 1 moves the bytes (csrc/decode_pair.h).  Same pixels, same verdicts on damaged chunks."""
