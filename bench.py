@@ -272,9 +272,21 @@ def main():
     filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[args.filter]
     p = hip.cparams(np.dtype(DTYPE).itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4 if args.codec == "lz4" else hip.BLOSCLZ, filters=(0, 0, 0, 0, 0, filt))
 
+    # One step = one pass of the hot path over the batch: compress every chunk, decompress every chunk, results (sizes,
+    # status words) on the host.  The two batches are enqueued back to back through the _begin / _fetch form of the
+    # device-resident calls (include/cimg_hip.h): the decode kernels follow the encode kernels in stream order, and the host's
+    # share -- planning, launches, the wait -- hides behind them (CIMG_BENCH_SYNC_CALLS=1: the plain calls, one wait each).
+    sync_calls = bool(os.environ.get("CIMG_BENCH_SYNC_CALLS"))
+
     def step():
-        cb = eng.compress_device(p, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
-        eng.decompress_device(d_comp.data_ptr(), comp_off, nbytes, blocksize, d_out.data_ptr(), raw_off)
+        if sync_calls:
+            cb = eng.compress_device(p, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
+            eng.decompress_device(d_comp.data_ptr(), comp_off, nbytes, blocksize, d_out.data_ptr(), raw_off)
+            return cb
+        n = eng.compress_device_begin(p, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
+        eng.decompress_device_begin(d_comp.data_ptr(), comp_off, nbytes, blocksize, d_out.data_ptr(), raw_off)
+        cb = eng.compress_device_fetch(n)
+        eng.decompress_device_fetch(n)
         return cb
 
     cbytes = step()
@@ -390,6 +402,8 @@ def main():
             "kernels": kernels,
             "exchange": exchange,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
+            "step_calls": ("cimg_compress_batch_device + cimg_decompress_batch_device (one wait each)" if sync_calls else
+                           "cimg_compress_batch_device_begin, cimg_decompress_batch_device_begin, then both _fetch (sizes and status on the host every step)"),
         }
         if not args.no_cpu_baseline and world == 1 and args.filter == "shuffle" and args.config == 2 and args.codec == "lz4":
             out["cpu_baseline"] = cpu_baseline(host, budget_s=10.0, policy="all_cores")

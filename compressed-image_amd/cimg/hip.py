@@ -24,6 +24,7 @@ EXPORTS = (
     "cimg_engine_synchronize", "cimg_engine_lock", "cimg_engine_unlock", "cimg_engine_stream", "cimg_compress_batch_device",
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host", "cimg_decompress_batch_host_sized",
     "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
+    "cimg_compress_batch_device_begin", "cimg_compress_batch_device_fetch", "cimg_decompress_batch_device_begin", "cimg_decompress_batch_device_fetch",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
     "cimg_engine_debug_stamps", "cimg_engine_read_stamps", "cimg_shared_engine", "cimg_context_cparams",
@@ -84,6 +85,10 @@ def load():
     L.cimg_engine_stream.restype = vp
     L.cimg_compress_batch_device.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_decompress_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_compress_batch_device_begin.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.cimg_compress_batch_device_fetch.argtypes = [vp, C.c_int32, vp]
+    L.cimg_decompress_batch_device_begin.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.cimg_decompress_batch_device_fetch.argtypes = [vp, vp]
     L.cimg_compress_batch_host.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_decompress_batch_host.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.cimg_decompress_batch_host_sized.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
@@ -221,6 +226,31 @@ class Engine:
         status = np.zeros(nbytes.size, np.int32)
         rc = load().cimg_decompress_batch_device(self.handle, nbytes.size, d_comp, _ptr(comp_off), _ptr(nbytes), _ptr(blocksize),
                                                  d_raw, _ptr(raw_off), _ptr(status))
+        if check:
+            self._check(rc)
+        return status
+
+    # the same in two steps (include/cimg_hip.h): the kernels of one compress and one decompress batch may be in flight together
+    def compress_device_begin(self, p, d_raw, raw_off, nbytes, d_comp, comp_off, destsize):
+        raw_off, comp_off, nbytes, destsize = _i64(raw_off), _i64(comp_off), _i32(nbytes), _i32(destsize)
+        self._check(load().cimg_compress_batch_device_begin(self.handle, C.byref(p), nbytes.size, d_raw, _ptr(raw_off), _ptr(nbytes),
+                                                            d_comp, _ptr(comp_off), _ptr(destsize)))
+        return nbytes.size
+
+    def compress_device_fetch(self, nchunks):
+        cbytes = np.zeros(nchunks, np.int32)
+        self._check(load().cimg_compress_batch_device_fetch(self.handle, nchunks, _ptr(cbytes)))
+        return cbytes
+
+    def decompress_device_begin(self, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off):
+        raw_off, comp_off, nbytes, blocksize = _i64(raw_off), _i64(comp_off), _i32(nbytes), _i32(blocksize)
+        self._check(load().cimg_decompress_batch_device_begin(self.handle, nbytes.size, d_comp, _ptr(comp_off), _ptr(nbytes), _ptr(blocksize),
+                                                              d_raw, _ptr(raw_off)))
+        return nbytes.size
+
+    def decompress_device_fetch(self, nchunks, check=True):
+        status = np.zeros(nchunks, np.int32)
+        rc = load().cimg_decompress_batch_device_fetch(self.handle, _ptr(status))
         if check:
             self._check(rc)
         return status

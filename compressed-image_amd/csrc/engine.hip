@@ -200,7 +200,7 @@ struct cimg_engine {
     int enc_block_items = getenv("CIMG_ENC_BLOCK_ITEMS") ? atoi(getenv("CIMG_ENC_BLOCK_ITEMS")) : -1;   // -1: by batch size
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
-    PinBuf h_descs, h_out;
+    PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
     bool lean_pair = getenv("CIMG_LEAN_PAIR") != nullptr && atoi(getenv("CIMG_LEAN_PAIR")) != 0;   // two waves per lean block (decode_pair.h)
     int max_dyn_lds[5] = {0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
     bool timing = false;              // events around the kernels of the current batch call
@@ -220,6 +220,8 @@ struct cimg_engine {
         size_t st_bytes = 0;
         DecodeArgs da{};
     } dflight;
+    bool dflight_open = false;            // between cimg_decompress_batch_device_begin and _fetch
+    int32_t cflight_chunks = -1;          // chunks of the compress batch between _device_begin and _device_fetch (-1: none)
 
     int fail(int code, const char* fmt, ...)
     {
@@ -256,16 +258,17 @@ struct cimg_engine {
         return rc;
     }
     // descriptors -> device, unless the device copy already holds exactly these bytes
-    int upload_descs(DevBuf& dev, std::vector<uint8_t>& shadow, const void* src, size_t bytes)
+    int upload_descs(DevBuf& dev, std::vector<uint8_t>& shadow, PinBuf& staging, const void* src, size_t bytes)
     {
         if (shadow.size() == bytes && dev.p && memcmp(shadow.data(), src, bytes) == 0) return 0;
         int rc;
         shadow.clear();
         if ((rc = reserve(dev, bytes))) return rc;
-        if ((rc = reserve(h_descs, bytes))) return rc;
-        memcpy(h_descs.p, src, bytes);
-        // every batch call ends with a stream synchronize, so h_descs is free again before the next upload
-        if ((rc = hip(hipMemcpyAsync(dev.p, h_descs.p, bytes, hipMemcpyHostToDevice, stream), "descs H2D"))) return rc;
+        if ((rc = reserve(staging, bytes))) return rc;
+        memcpy(staging.p, src, bytes);
+        // every batch of one kind ends with a stream synchronize before the next of its kind begins, so its staging
+        // buffer is free again
+        if ((rc = hip(hipMemcpyAsync(dev.p, staging.p, bytes, hipMemcpyHostToDevice, stream), "descs H2D"))) return rc;
         shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
         return 0;
     }
@@ -409,7 +412,7 @@ void cimg_engine_destroy(cimg_engine* e)
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue, &e->done})
         if (b->p) (void)hipFree(b->p);
-    for (PinBuf* b : {&e->h_descs, &e->h_out})
+    for (PinBuf* b : {&e->h_descs, &e->h_descs_dec, &e->h_out, &e->h_dec})
         if (b->p) (void)hipHostFree(b->p);
     (void)hipStreamDestroy(e->stream);
     if (e->s_h2d) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamDestroy(e->s_h2d); }
@@ -521,7 +524,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     if (rc < 0) return e->fail(rc, "compress batch rejected by the planner (code %d): codec %d / filter pipeline / block size %d not available on the GPU path",
                                rc, p->compcode, p->blocksize);
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
-    if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, plan.descs.data(), desc_bytes))) return rc;
+    if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, e->h_descs, plan.descs.data(), desc_bytes))) return rc;
     if ((rc = e->reserve(e->recs, sizeof(StreamRec) * (size_t)plan.total_blocks * plan.cp.streams_per_block))) return rc;
     if ((rc = e->reserve(e->layout, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
     if ((rc = e->reserve(e->h_out, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
@@ -619,8 +622,33 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    e->cflight_chunks = -1;
     const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize);
     return rc ? rc : compress_finish(e, nchunks, cbytes);
+}
+
+int cimg_compress_batch_device_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                                     const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
+                                     void* d_comp, const int64_t* comp_off, const int32_t* destsize)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    e->cflight_chunks = -1;
+    if (nchunks <= 0) { e->cflight_chunks = 0; return 0; }
+    if (!p || !raw_off || !nbytes || !comp_off || !destsize) return e->fail(ERR_INVALID_PARAM, "null argument");
+    const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize);
+    if (!rc) e->cflight_chunks = nchunks;
+    return rc;
+}
+
+int cimg_compress_batch_device_fetch(cimg_engine* e, int32_t nchunks, int32_t* cbytes)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    if (e->cflight_chunks < 0 || e->cflight_chunks != nchunks)
+        return e->fail(ERR_INVALID_PARAM, "no compress batch of %d chunks is in flight (cimg_compress_batch_device_begin comes first)", nchunks);
+    e->cflight_chunks = -1;
+    if (nchunks == 0) return 0;
+    if (!cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    return compress_finish(e, nchunks, cbytes);
 }
 
 // the kernels of one decode batch, enqueued on the engine's stream; decompress_finish() waits, launches the general
@@ -636,11 +664,11 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     if (plan.lds_lean > 0) plan.lds_lean += e->lean_lds_pad;
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
     const size_t st_bytes = sizeof(int32_t) * (size_t)nchunks;
-    if ((rc = e->upload_descs(e->descs_dec, e->shadow_dec, plan.descs.data(), desc_bytes))) return rc;
-    if ((rc = e->reserve(e->h_out, st_bytes + 32))) return rc;
+    if ((rc = e->upload_descs(e->descs_dec, e->shadow_dec, e->h_descs_dec, plan.descs.data(), desc_bytes))) return rc;
+    if ((rc = e->reserve(e->h_dec, st_bytes + 32))) return rc;
     int32_t* st_dev = nullptr;                    // the status words live in pinned host memory; only failing blocks write
-    if ((rc = e->device_alias(e->h_out, &st_dev))) return rc;
-    memset(e->h_out.p, 0, st_bytes);
+    if ((rc = e->device_alias(e->h_dec, &st_dev))) return rc;
+    memset(e->h_dec.p, 0, st_bytes);
     uint64_t* dbg = nullptr;
     if (e->stamps) {
         if ((rc = e->reserve(e->dbg, (size_t)plan.total_blocks * 128))) return rc;
@@ -669,7 +697,7 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
             e->done_gen = 1;
         }
         done = (uint32_t*)e->done.p;
-        skipped_host = (volatile uint32_t*)((uint8_t*)e->h_out.p + ((st_bytes + 15) & ~(size_t)15));
+        skipped_host = (volatile uint32_t*)((uint8_t*)e->h_dec.p + ((st_bytes + 15) & ~(size_t)15));
         *skipped_host = 0;
         skipped_dev = (uint32_t*)((uint8_t*)st_dev + ((st_bytes + 15) & ~(size_t)15));
     }
@@ -722,7 +750,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     const int32_t nchunks = f.nchunks;
     const DecodeArgs da = f.da;
     struct { int32_t total_blocks, lds_bytes; } plan{f.total_blocks, f.lds_bytes};
-    volatile uint32_t* skipped_host = (volatile uint32_t*)((uint8_t*)e->h_out.p + ((f.st_bytes + 15) & ~(size_t)15));
+    volatile uint32_t* skipped_host = (volatile uint32_t*)((uint8_t*)e->h_dec.p + ((f.st_bytes + 15) & ~(size_t)15));
     int rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
     if (lean) {
@@ -743,7 +771,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
             if ((rc = cimg_engine_synchronize(e))) return rc;
         }
     }
-    const int32_t* st = (const int32_t*)e->h_out.p;
+    const int32_t* st = (const int32_t*)e->h_dec.p;
     int first = 0;
     for (int i = 0; i < nchunks; i++) {
         if (status) status[i] = st[i];
@@ -760,8 +788,31 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    e->dflight_open = false;
     const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off);
     return rc ? rc : decompress_finish(e, status);
+}
+
+int cimg_decompress_batch_device_begin(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
+                                       const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    e->dflight_open = false;
+    e->dflight.nchunks = 0;
+    if (nchunks <= 0) { e->dflight_open = true; return 0; }
+    if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
+    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off);
+    if (!rc) e->dflight_open = true;
+    return rc;
+}
+
+int cimg_decompress_batch_device_fetch(cimg_engine* e, int32_t* status)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    if (!e->dflight_open) return e->fail(ERR_INVALID_PARAM, "no decompress batch is in flight (cimg_decompress_batch_device_begin comes first)");
+    e->dflight_open = false;
+    if (e->dflight.nchunks <= 0) return 0;
+    return decompress_finish(e, status);
 }
 
 // ---- host-resident batches: stage through device buffers owned by the engine -----------------------

@@ -70,6 +70,23 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks,
                                  const int32_t* nbytes, const int32_t* blocksize,
                                  void* d_raw, const int64_t* raw_off, int32_t* status);
 
+/* The same in two steps: _begin enqueues the kernels on the engine's stream and returns at once, _fetch waits for them
+ * and hands over the results.  ONE compress batch and ONE decompress batch may be in flight together, and a decompress
+ * _begin may follow the compress _begin of the chunks it reads directly (stream order: it sees them finished; nbytes /
+ * blocksize are the caller's, nothing of the compress results is needed on the host) -- so the host's share of a round
+ * trip (planning, launches, the wait) hides behind the kernels instead of leaving the GPU idle between the calls.
+ * Each _fetch refers to the most recent _begin of its kind; a plain batch call of the same kind in between invalidates
+ * it (error).  Threads sharing an engine hold cimg_engine_lock from _begin to _fetch. */
+int cimg_compress_batch_device_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
+                                     const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
+                                     void* d_comp, const int64_t* comp_off, const int32_t* destsize);
+int cimg_compress_batch_device_fetch(cimg_engine* e, int32_t nchunks, int32_t* cbytes);
+int cimg_decompress_batch_device_begin(cimg_engine* e, int32_t nchunks,
+                                       const void* d_comp, const int64_t* comp_off,
+                                       const int32_t* nbytes, const int32_t* blocksize,
+                                       void* d_raw, const int64_t* raw_off);
+int cimg_decompress_batch_device_fetch(cimg_engine* e, int32_t* status);
+
 /* ---- host-resident batches (H2D + kernels + D2H inside) ------------------------------------------ */
 int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
                              const void* h_raw, const int64_t* raw_off, const int32_t* nbytes,

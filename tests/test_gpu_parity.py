@@ -398,6 +398,43 @@ def test_encode_automatic_gang_on_a_batch_that_fills_the_device(eng):
     assert np.array_equal(np.concatenate(outs), raw)
 
 
+def test_device_batches_in_two_steps_overlap_and_refuse_misuse(eng):
+    """cimg_*_batch_device_begin / _fetch: a decompress batch is enqueued right behind the compress batch whose chunks it
+    reads, before anything of the compress results has reached the host; sizes, bytes and pixels are those of the plain
+    calls.  A _fetch without its _begin, or after a plain call of the same kind, is an error, not a hang."""
+    a = synth.tiled_channel(np.float16, 2048, 1024)                     # 4 MiB -> 4 chunks of 1 MiB
+    raw = a.view(np.uint8).ravel()
+    chunk, n = 1 << 20, 4
+    stride = chunk + 64
+    d_raw, d_comp, d_out = eng.alloc(raw.size), eng.alloc(n * stride), eng.alloc(raw.size)
+    d_raw.upload(raw)
+    raw_off, comp_off = np.arange(n) * chunk, np.arange(n) * stride
+    p = hip.cparams(2)
+    plain = eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * n, d_comp.ptr, comp_off, [chunk + 32] * n)
+    for rep in range(3):
+        k = eng.compress_device_begin(p, d_raw.ptr, raw_off, [chunk] * n, d_comp.ptr, comp_off, [chunk + 32] * n)
+        eng.decompress_device_begin(d_comp.ptr, comp_off, [chunk] * n, [32768] * n, d_out.ptr, raw_off)
+        cb = eng.compress_device_fetch(k)
+        st = eng.decompress_device_fetch(k)
+        assert np.array_equal(cb, plain) and not st.any()
+        assert np.array_equal(d_out.download(), raw)
+    comp = d_comp.download()
+    for i in range(n):
+        rc, want = O.compress(O.cparams(2), raw[i * chunk:(i + 1) * chunk])
+        assert rc == cb[i] and want == comp[i * stride:i * stride + rc].tobytes()
+    with pytest.raises(hip.CodecError):
+        eng.compress_device_fetch(n)                                     # nothing in flight
+    with pytest.raises(hip.CodecError):
+        eng.decompress_device_fetch(n)
+    eng.compress_device_begin(p, d_raw.ptr, raw_off, [chunk] * n, d_comp.ptr, comp_off, [chunk + 32] * n)
+    eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * n, d_comp.ptr, comp_off, [chunk + 32] * n)   # a plain call in between
+    with pytest.raises(hip.CodecError):
+        eng.compress_device_fetch(n)
+    with pytest.raises(hip.CodecError):
+        eng.compress_device_begin(p, d_raw.ptr, raw_off, [chunk] * n, d_comp.ptr, comp_off, [chunk + 32] * n) and eng.compress_device_fetch(n + 1)
+    eng.synchronize()
+
+
 def test_two_wave_lean_decode_gives_the_same_pixels():
     """CIMG_LEAN_PAIR=1 (read when an engine is created): the lean decode launch with two waves per block -- wave 0 finds
     the tokens of the LZ4 chain, wave 1 moves the bytes (csrc/decode_pair.h).  Same pixels, same verdicts on damaged chunks."""
