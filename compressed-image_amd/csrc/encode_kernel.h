@@ -328,14 +328,14 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
             const bool dense = t0 == 0 && s64 == 64;
             int ip = 0, mp = 0, mcode = 0, backrun = 0;
-            bool zero_lit = false, have_match = false, extended = false;
+            bool zero_lit = false;
             // ---- run fast path (a lambda: used by the scalar head below and, near the end of a stream, after the layout)
             // The probe right after a match very often lands on the first byte of a run (flat image areas:
             // high byte planes, masks, alpha).  Then probe 0 of the new search has the same four bytes, the
             // same hash and -- unless the post-match probe itself matches -- is a match at offset 1.  That
             // outcome needs only the post-match probe's own table slot, so the 64-lane window machinery is
             // skipped: slot read + run-length scan in one LDS round trip, candidate check in a second.
-            auto run_path = [&](const uint32_t v0, const uint32_t backv) -> int {
+            auto run_path = [&](const uint32_t v0, const uint32_t backv) {
                 const int ip0 = sstart - 1;
                 const uint32_t h0 = lz4_hash(v0);
                 const uint32_t bbbb = (v0 & 0xFF) * 0x01010101u;            // v0 == v1 means v0 is four equal bytes
@@ -356,13 +356,12 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     iw[l] = lds_ld32u(in, ip0 + 4 * l);
                 }
                 const bool hit0 = readlane(cw, 0) == v0;
-                have_match = true;
                 CIMG_STAT(g_emu_matches);
                 if (hit0) {
                     CIMG_PROF_COUNT(5);
                     // zero-literal match at the post-match probe
                     FOR_LANES_W(l) { tab16[h0] = (uint16_t)ip0; }
-                    ip = ip0; mp = old0; zero_lit = true; extended = true; backrun = 0;
+                    ip = ip0; mp = old0; zero_lit = true; backrun = 0;
                     const int maxc = matchlimit - (ip0 + 4);
                     LV<int> len;
                     LV<bool> stop;
@@ -378,12 +377,11 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     else mcode = match_more(in, ip0, old0, maxc, 252, n);
                 } else {
                     FOR_LANES_W(l) { tab16[h0] = (uint16_t)(ip0 + 1); }
-                    ip = ip0 + 1; mp = ip0; zero_lit = false; extended = true;
+                    ip = ip0 + 1; mp = ip0; zero_lit = false;
                     backrun = (readlane(before, 0) == (v0 & 0xFF)) ? 1 : 0;      // room is min(ip - anchor, mp) = 1
                     // offset-1 match: it runs to the end of the run (or matchlimit)
                     const int maxc = matchlimit - (ip + 4);
-                    for (int scans = 0;; ++scans) {
-                        if (scans > n / 256 + 2) return -2;
+                    for (int scans = 0; scans <= n / 256 + 2; ++scans) {              // bounded: 256 bytes a step, the run ends at matchlimit
                         LV<int> len;
                         LV<bool> stop;
                         FOR_LANES(l) {
@@ -405,8 +403,77 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         FOR_LANES(l) { scan[l] = lds_ld32u(in, ip + 4 + mcode + 4 * l); }
                     }
                 }
-                return 0;
             };
+            // ---- a match at ip with candidate mp: (unless the path that found it already did) extend it both ways with one LDS
+            // round trip, park the sequence, set the next search up.  Called from every place a match is found, each of
+            // which knows statically whether the extension is done -- no flags travel through the loop.
+            // Returns 0: go on, 1: the plane is finished, 2: the output does not fit.
+            const auto sequence = [&](auto extended_tag, int ip, int mp, int mcode, int backrun, const bool zero_lit) -> int {
+            if constexpr (!decltype(extended_tag)::value) {
+            CIMG_PROF_COUNT(3);
+            const int room = zero_lit ? 0 : imin(ip - anchor, mp);
+            const int maxc = matchlimit - (ip + 4);
+                LV<bool> eq, stop;
+                LV<int> len;
+                // No guards around the loads: bytes past the plane end are readable (the hash table follows
+                // it in LDS) and lanes past matchlimit are cut by the min with vb, so both directions go out
+                // in ONE LDS round trip.
+                FOR_LANES(l) {
+                    const int kb = l < room ? l + 1 : 0;
+                    const uint32_t pa = in[ip - kb], pb = in[mp - kb];
+                    const int k = 4 * l;
+                    const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
+                    eq[l] = (l < room) & (pa == pb);
+                    const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
+                    len[l] = ln;
+                    stop[l] = ln < 4;
+                }
+                backrun = ctz64(~ballot(eq));
+                const uint64_t sm = ballot(stop);
+                if (sm) {
+                    const int f = ctz64(sm);
+                    mcode = 4 * f + readlane(len, f);
+                } else {
+                    CIMG_PROF_COUNT(4);
+                    mcode = match_more(in, ip, mp, maxc, 256, n);         // long match: keep counting, 256 bytes a step
+                }
+                if (backrun == 64) {                              // rare: more than 64 bytes backwards
+                    int left = room - 64;
+                    while (left > 0) {
+                        FOR_LANES(l) { eq[l] = l < left && in[ip - 1 - backrun - l] == in[mp - 1 - backrun - l]; }
+                        const int r = ctz64(~ballot(eq));
+                        backrun += r; left -= r;
+                        if (r < 64) break;
+                    }
+                }
+            }   // not extended yet
+            CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);               // match extension
+            ip -= backrun; mp -= backrun; mcode += backrun;
+            const int lit = zero_lit ? 0 : ip - anchor;
+            // the ten bytes the scalar head of the NEXT search needs sit at the end of this match: request them now, so
+            // that the LDS round trip runs behind the bookkeeping below instead of in front of the next search
+            FOR_LANES(l) { Wn[l] = lds_ld32u(in, ip + mcode + 4 - 2 + 4 * (l < 2 ? l : 2)); }
+            // ---- park the sequence; budget checks and stores happen 64 sequences at a time -------------------
+            {
+                const int slot = np;
+                FOR_LANES(l) {
+                    if (l == slot) { P_anchor[l] = anchor; P_lit[l] = lit; P_off[l] = ip - mp; P_mcode[l] = mcode; }
+                }
+                if (++np == 64) {
+                    if (!emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) return 2;
+                    np = 0;
+                }
+            }
+            ip += mcode + 4;
+            anchor = ip;
+            CIMG_PROF_LAP(5);                                   // budget checks + emit
+            if (ip >= mflimit_p1) return 1;
+            sstart = ip + 1;
+            t0 = 0;
+            pre = 1;
+            return 0;
+            };
+#define CIMG_SEQUENCE(EXT) { const int r_ = sequence(std::EXT##_type{}, ip, mp, mcode, backrun, zero_lit); if (r_) { if (r_ == 2) ending = 0; break; } continue; }
             // ---- scalar head ------------------------------------------------------------------------------------
             // Right after a match the next match is nearly always found by the post-match probe or one of the
             // first two probes of the new search (tiled family: 114 of 129 sequences, natural: 99 %).  Those three
@@ -420,9 +487,9 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 const uint32_t v0 = (w0 >> 16) | (w1 << 16), v1 = (w0 >> 24) | (w1 << 8), v2 = w1;   // bytes at ip0, ip0 + 1, ip0 + 2
                 CIMG_PROF_LAP(1);
                 if (v0 == v1) {
-                    const int rc_ = run_path(v0, w0);
-                    if (rc_ < 0) { ending = rc_; break; }
+                    run_path(v0, w0);
                     CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0);
+                    CIMG_SEQUENCE(true)
                 } else {
                     const uint32_t h0 = lz4_hash(v0), h1 = lz4_hash(v1), h2 = lz4_hash(v2);
                     // a probe whose hash equals an EARLIER probe's would have to see that probe's write: only hits before
@@ -444,15 +511,15 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         ip = ip0 + m3;
                         mp = (int)readlane(old3, m3);
                         zero_lit = m3 == 0;
-                        have_match = true;
                         CIMG_STAT(g_emu_matches);
                         CIMG_PROF_COUNT(7);
+                        CIMG_PROF_LAP(7);
+                        CIMG_SEQUENCE(false)
                     }
                     CIMG_PROF_LAP(7);
                 }
             }
             int nv = 64;                                          // valid lanes are a prefix
-            if (!have_match) {
             if (dense) {
                 // first window of a search at acceleration 1 (every window right after a match): probe t sits at
                 // sstart + t with gap 1, so the valid prefix is known without looking at the lanes
@@ -485,15 +552,18 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             // near the end of a stream the scalar head is not taken: the run path from the laid-out lanes
             if (pre && nv >= 2) {
                 const uint32_t v0 = readlane(v, 0), v1 = readlane(v, 1);
-                if (v0 == v1) { const int rc_ = run_path(v0, readlane(back, 0)); if (rc_ < 0) { ending = rc_; break; } }
+                if (v0 == v1) {
+                    run_path(v0, readlane(back, 0));
+                    CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0);
+                    CIMG_SEQUENCE(true)
+                }
             }
-            if (have_match) { CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0); }   // run path
             // ---- narrow path ----------------------------------------------------------------------------------
             // In compressible data the next match is almost always found by the post-match probe or one of the
             // first probes of the new search.  With pairwise different hashes among those few probes, sequential
             // LZ4 and "read all slots, then write" agree, so the 64-lane collision machinery is not needed:
             // slots in one LDS round trip, candidates in a second, writes only for the probes actually consumed.
-            if (!have_match && !headed && pre && nv >= 4) {
+            if (!headed && pre && nv >= 4) {
                 FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
                 LV<uint32_t> h1, h2, h3, old4;
                 lane_prev(h, h1);
@@ -521,11 +591,10 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         ip = readlane(pos, m4);
                         mp = (int)readlane(old4, m4);
                         zero_lit = m4 == 0;
-                        have_match = true;
                         CIMG_STAT(g_emu_matches);
                         CIMG_PROF_COUNT(7);
                         if (m4 == 0) {
-                            extended = true; backrun = 0;
+                            backrun = 0;
                             const int maxc = matchlimit - (p0 + 4);
                             LV<int> len;
                             LV<bool> stop;
@@ -538,12 +607,15 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                             const uint64_t sm = ballot(stop);
                             if (sm) { const int f = ctz64(sm); mcode = 4 * f + readlane(len, f); }
                             else mcode = match_more(in, p0, c0, maxc, 256, n);
+                            CIMG_PROF_LAP(7);
+                            CIMG_SEQUENCE(true)
                         }
+                        CIMG_PROF_LAP(7);
+                        CIMG_SEQUENCE(false)
                     }
                 }
                 CIMG_PROF_LAP(7);
             }
-            if (!have_match) {
             if (pre) { FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; } }
             // a lane with the same hash as its left neighbour has that neighbour as candidate
             LV<uint32_t> ph, pv;
@@ -607,73 +679,9 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             ip = readlane(pos, m);
             mp = readlane(cand, m);
             zero_lit = pre && m == 0;
-            }   // !have_match (window path)
-            }   // !have_match (layout, late run path, narrow path, window path)
-
-            // ---- a match at ip with candidate mp: extend both ways with one LDS round trip ---------------------
-            if (!extended) {
-            CIMG_PROF_COUNT(3);
-            const int room = zero_lit ? 0 : imin(ip - anchor, mp);
-            const int maxc = matchlimit - (ip + 4);
-                LV<bool> eq, stop;
-                LV<int> len;
-                // No guards around the loads: bytes past the plane end are readable (the hash table follows
-                // it in LDS) and lanes past matchlimit are cut by the min with vb, so both directions go out
-                // in ONE LDS round trip.
-                FOR_LANES(l) {
-                    const int kb = l < room ? l + 1 : 0;
-                    const uint32_t pa = in[ip - kb], pb = in[mp - kb];
-                    const int k = 4 * l;
-                    const uint32_t x = lds_ld32u(in, ip + 4 + k) ^ lds_ld32u(in, mp + 4 + k);
-                    eq[l] = (l < room) & (pa == pb);
-                    const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
-                    len[l] = ln;
-                    stop[l] = ln < 4;
-                }
-                backrun = ctz64(~ballot(eq));
-                const uint64_t sm = ballot(stop);
-                if (sm) {
-                    const int f = ctz64(sm);
-                    mcode = 4 * f + readlane(len, f);
-                } else {
-                    CIMG_PROF_COUNT(4);
-                    mcode = match_more(in, ip, mp, maxc, 256, n);         // long match: keep counting, 256 bytes a step
-                }
-                if (backrun == 64) {                              // rare: more than 64 bytes backwards
-                    int left = room - 64;
-                    while (left > 0) {
-                        FOR_LANES(l) { eq[l] = l < left && in[ip - 1 - backrun - l] == in[mp - 1 - backrun - l]; }
-                        const int r = ctz64(~ballot(eq));
-                        backrun += r; left -= r;
-                        if (r < 64) break;
-                    }
-                }
-            }   // !extended
-            CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);               // match extension
-            ip -= backrun; mp -= backrun; mcode += backrun;
-            const int lit = zero_lit ? 0 : ip - anchor;
-            // the ten bytes the scalar head of the NEXT search needs sit at the end of this match: request them now, so
-            // that the LDS round trip runs behind the bookkeeping below instead of in front of the next search
-            FOR_LANES(l) { Wn[l] = lds_ld32u(in, ip + mcode + 4 - 2 + 4 * (l < 2 ? l : 2)); }
-            // ---- park the sequence; budget checks and stores happen 64 sequences at a time -------------------
-            {
-                const int slot = np;
-                FOR_LANES(l) {
-                    if (l == slot) { P_anchor[l] = anchor; P_lit[l] = lit; P_off[l] = ip - mp; P_mcode[l] = mcode; }
-                }
-                if (++np == 64) {
-                    if (!emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) { ending = 0; break; }
-                    np = 0;
-                }
-            }
-            ip += mcode + 4;
-            anchor = ip;
-            CIMG_PROF_LAP(5);                                   // budget checks + emit
-            if (ip >= mflimit_p1) break;
-            sstart = ip + 1;
-            t0 = 0;
-            pre = 1;
+            CIMG_SEQUENCE(false)
         }
+#undef CIMG_SEQUENCE
         if (ending <= 0) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return ending; }
     }
     if (np && !emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return 0; }
