@@ -314,19 +314,18 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
         int pre = 0;        // 1: lane 0 is the probe right after a match (position sstart - 1)
         LV<uint32_t> Wn;    // bytes [ip - 2, ip + 10) around the end of the last match, lanes 0..2 (scalar head)
         FOR_LANES(l) { Wn[l] = 0; }
-        int guard = 0;      // every wave must reach an exit: a window commits at least one probe, so n + 2 windows is a hard bound
+        int guard = 0;      // every wave must reach an exit: a window commits at least one probe, a head iteration finds a match (>= 4 bytes)
+                            // or is followed by a window, so 2 n + 4 iterations is a hard bound
         // ONE way out of the loop: every exit is a `break` with `ending` saying why.  With returns inside the loop the compiler
         // unifies the exits through a selector that EVERY iteration is then dispatched on (≈ 20 scalar instructions and
         // three taken branches per sequence).
         int ending = 1;     // 1: the search reached the end of the plane; 0: the output does not fit; < 0: a loop guard tripped
         for (;;) {
-            if (++guard > n + 2) { ending = -1; break; }
+            if (++guard > 2 * n + 4) { ending = -1; break; }
             // ---- lay the window out ------------------------------------------------------------------
             LV<int> pos;
             LV<bool> valid;
             LV<uint32_t> v, h, back;
-            const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
-            const bool dense = t0 == 0 && s64 == 64;
             int ip = 0, mp = 0, mcode = 0, backrun = 0;
             bool zero_lit = false;
             // ---- run fast path (a lambda: used by the scalar head below and, near the end of a stream, after the layout)
@@ -339,7 +338,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 const int ip0 = sstart - 1;
                 const uint32_t h0 = lz4_hash(v0);
                 const uint32_t bbbb = (v0 & 0xFF) * 0x01010101u;            // v0 == v1 means v0 is four equal bytes
-                FOR_LANES_W(l) { tab16[lz4_hash(backv)] = (uint16_t)backpos; }
+                FOR_LANES_W(l) { tab16[lz4_hash(backv)] = (uint16_t)(sstart - 3); }   // the "put(ip - 2)" refill (pre == 1 on every call)
                 LV<uint32_t> slot, scan;
                 LV<uint32_t> before;
                 FOR_LANES(l) {
@@ -377,7 +376,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     else mcode = match_more(in, ip0, old0, maxc, 252, n);
                 } else {
                     FOR_LANES_W(l) { tab16[h0] = (uint16_t)(ip0 + 1); }
-                    ip = ip0 + 1; mp = ip0; zero_lit = false;
+                    ip = ip0 + 1; mp = ip0; zero_lit = false; mcode = 0;
                     backrun = (readlane(before, 0) == (v0 & 0xFF)) ? 1 : 0;      // room is min(ip - anchor, mp) = 1
                     // offset-1 match: it runs to the end of the run (or matchlimit)
                     const int maxc = matchlimit - (ip + 4);
@@ -473,15 +472,18 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             pre = 1;
             return 0;
             };
+#define CIMG_SEQUENCE_IN_HEAD(EXT) { const int r_ = sequence(std::EXT##_type{}, ip, mp, mcode, backrun, zero_lit); if (r_) { if (r_ == 2) ending = 0; stop = true; break; } continue; }
 #define CIMG_SEQUENCE(EXT) { const int r_ = sequence(std::EXT##_type{}, ip, mp, mcode, backrun, zero_lit); if (r_) { if (r_ == 2) ending = 0; break; } continue; }
             // ---- scalar head ------------------------------------------------------------------------------------
             // Right after a match the next match is nearly always found by the post-match probe or one of the
             // first two probes of the new search (tiled family: 114 of 129 sequences, natural: 99 %).  Those three
             // need 10 input bytes: one LDS round trip brings them into scalars, and the run path / a three-probe
             // version of the narrow path below run without laying out a 64-probe window at all.
-            bool headed = false;
-            if (pre && dense && mflimit_p1 - sstart >= 3) {
-                headed = true;
+            // The head is a LOOP of its own: as long as it keeps finding the next match, sequence follows sequence in here and
+            // none of the window state of the outer iteration is touched.
+            bool headed = false, stop = false;
+            while (pre && t0 == 0 && s64 == 64 && mflimit_p1 - sstart >= 3) {
+                if (++guard > 2 * n + 4) { ending = -1; stop = true; break; }
                 const int ip0 = sstart - 1;
                 const uint32_t w0 = readlane(Wn, 0), w1 = readlane(Wn, 1);     // requested when the previous match was parked
                 const uint32_t v0 = (w0 >> 16) | (w1 << 16), v1 = (w0 >> 24) | (w1 << 8), v2 = w1;   // bytes at ip0, ip0 + 1, ip0 + 2
@@ -489,13 +491,13 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 if (v0 == v1) {
                     run_path(v0, w0);
                     CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0);
-                    CIMG_SEQUENCE(true)
+                    CIMG_SEQUENCE_IN_HEAD(true)
                 } else {
                     const uint32_t h0 = lz4_hash(v0), h1 = lz4_hash(v1), h2 = lz4_hash(v2);
                     // a probe whose hash equals an EARLIER probe's would have to see that probe's write: only hits before
                     // the first such probe are taken ("read all slots, then write" equals sequential LZ4 up to there)
                     const int clean = h1 == h0 ? 1 : ((h2 == h0 || h2 == h1) ? 2 : 3);    // probes 0 .. clean - 1 have pairwise different hashes
-                    FOR_LANES_W(l) { tab16[lz4_hash(w0)] = (uint16_t)backpos; }
+                    FOR_LANES_W(l) { tab16[lz4_hash(w0)] = (uint16_t)(sstart - 3); }
                     LV<uint32_t> hl, vl, old3;
                     LV<bool> hit3;
                     FOR_LANES(l) {
@@ -514,11 +516,16 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                         CIMG_STAT(g_emu_matches);
                         CIMG_PROF_COUNT(7);
                         CIMG_PROF_LAP(7);
-                        CIMG_SEQUENCE(false)
+                        CIMG_SEQUENCE_IN_HEAD(false)
                     }
                     CIMG_PROF_LAP(7);
                 }
+                headed = true;                                    // three probes, no match: on to the window, which holds them again
+                break;
             }
+            if (stop) break;
+            const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
+            const bool dense = t0 == 0 && s64 == 64;
             int nv = 64;                                          // valid lanes are a prefix
             if (dense) {
                 // first window of a search at acceleration 1 (every window right after a match): probe t sits at
@@ -682,6 +689,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             CIMG_SEQUENCE(false)
         }
 #undef CIMG_SEQUENCE
+#undef CIMG_SEQUENCE_IN_HEAD
         if (ending <= 0) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return ending; }
     }
     if (np && !emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return 0; }
