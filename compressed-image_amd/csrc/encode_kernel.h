@@ -482,7 +482,8 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             // The head is a LOOP of its own: as long as it keeps finding the next match, sequence follows sequence in here and
             // none of the window state of the outer iteration is touched.
             bool headed = false, stop = false;
-            while (pre && t0 == 0 && s64 == 64 && mflimit_p1 - sstart >= 3) {
+            if (pre && t0 == 0 && s64 == 64)                      // (every sequence leaves pre == 1, t0 == 0: only the range is tested again)
+            while (mflimit_p1 - sstart >= 3) {
                 if (++guard > 2 * n + 4) { ending = -1; stop = true; break; }
                 const int ip0 = sstart - 1;
                 const uint32_t w0 = readlane(Wn, 0), w1 = readlane(Wn, 1);     // requested when the previous match was parked
