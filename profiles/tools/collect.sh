@@ -20,6 +20,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "S
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc_$name -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_$name.err
 done
 python3 profiles/tools/summarize_pmc.py $out > $out/pmc_per_launch.json
+# the plain bench below takes roofline.traffic from profiles/<tag>/pmc_per_launch.json when its source hash matches: put the fresh one there first
+mkdir -p profiles/$tag && cp $out/pmc_per_launch.json profiles/$tag/pmc_per_launch.json
 echo "[collect] plain bench"
 timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err
 cat $out/bench.json
