@@ -180,6 +180,9 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
     int np = 0, op = 0;
     int anchor = 0;                                                   // start of the literals not yet accounted for
 
+    // ONE way out of both loops (`break` with `ending` set): a return inside a loop makes the compiler dispatch every
+    // iteration on an exit selector (encode_kernel.h has the measurement)
+    int ending = 1;                                                   // 1: go on; 0: give up (stored raw); < 0: a loop guard tripped
     for (; pass < 3; ++pass) {
         const bool probe = pass < 2;
         if (pass == 2) {
@@ -188,7 +191,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
             ipshift = (clevel == 9 && csize3 < csize4) ? 3 : 4;
             const double cratio = (double)maxlen / (double)cs;
             const double thr = clevel <= 4 ? 2.0 : (clevel == 5 ? 1.8 : (clevel == 6 ? 1.6 : (clevel == 7 ? 1.4 : (clevel == 8 ? 1.2 : 1.1))));
-            if (cratio < thr) return 0;
+            if (cratio < thr) { ending = 0; break; }
         }
         const int shift = probe ? 32 - BLZ_HASH_LOG : 32 - hashlog;
         const int ips = probe ? (pass == 0 ? 3 : 4) : ipshift;
@@ -204,7 +207,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
         int oc = 5, copyc = 4;                                        // the probe's counters ("4 literals already copied")
         int guard = 0;
         while (ip < ip_limit) {
-            if (++guard > n + 2) return -1;                           // a window consumes at least one position
+            if (++guard > n + 2) { ending = -1; break; }              // a window consumes at least one position
             const int nv = imin(64, ip_limit - ip);
             LV<int> pos;
             LV<bool> valid;
@@ -295,7 +298,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
                 const int slot = np;
                 FOR_LANES(l) { if (l == slot) { P_anchor[l] = anchor; P_lit[l] = L; P_dist[l] = dist; P_len[l] = len; } }
                 if (++np == 64) {
-                    if (!blz_emit_pending(in, out, cap, op, np, P_anchor, P_lit, P_dist, P_len)) return 0;
+                    if (!blz_emit_pending(in, out, cap, op, np, P_anchor, P_lit, P_dist, P_len)) { ending = 0; break; }
                     np = 0;
                 }
             }
@@ -308,6 +311,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
             ip = nip + 2;
             anchor = ip;
         }
+        if (ending <= 0) break;
         if (probe) {
             // the dry run has no left-over loop: it stops at ip_limit, the literals it counted are those below it
             const int Lc = imax(ip_limit - anchor, 0);
@@ -317,6 +321,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
             if (pass == 0) csize3 = oc; else csize4 = oc;
         }
     }
+    if (ending <= 0) return ending;
     // ---- real pass: flush the parked sequences, then the left-over literals (at least one: the scan stops 12 bytes early)
     if (np && !blz_emit_pending(in, out, cap, op, np, P_anchor, P_lit, P_dist, P_len)) return 0;
     const int Lf = n - anchor;
