@@ -221,6 +221,7 @@ CIMG_DEV bool emit_pending(const uint8_t* in, cimg_global_u8p out, int cap, int&
 // wasted window.  Returns true when the search reached the end of the plane without a match: the block is its literals.
 CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n, int s64, int f64, int mflimit_p1)
 {
+    bool verdict = false;                                               // one way out of the loop (see lz4_encode_body)
     for (int t0 = 0; t0 <= n; t0 += 64) {                               // hard bound: a window commits 64 probes
         LV<int> pos;
         LV<bool> inside;
@@ -232,7 +233,7 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
             inside[l] = p + gap <= mflimit_p1;
         }
         const uint64_t in_mask = ballot(inside);                         // a prefix of the lanes
-        if (!in_mask) return true;
+        if (!in_mask) { verdict = true; break; }
         LV<uint32_t> v, h, old, rb, cv;
         LV<bool> lost, equal;
         FOR_LANES(l) { v[l] = lds_ld32u(in, inside[l] ? pos[l] : 0); h[l] = lz4_hash(v[l]); }
@@ -243,7 +244,7 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
             lost[l] = inside[l] & (rb[l] != (uint32_t)(uint16_t)pos[l]);
             equal[l] = inside[l] & (cv[l] == v[l]);
         }
-        if (ballot(equal)) return false;
+        if (ballot(equal)) break;
         if (ballot(lost)) {
             // the lanes that lost their slot write again: one loser per slot means pairs, and its second read-back is its own
             LV<uint32_t> rb2, wv;
@@ -254,14 +255,14 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
                 crowd[l] = lost[l] & (rb2[l] != (uint32_t)(uint16_t)pos[l]);
                 same[l] = lost[l] & (wv[l] == v[l]);                     // the other probe of the pair has the same four bytes
             }
-            if (ballot(crowd) | ballot(same)) return false;
+            if (ballot(crowd) | ballot(same)) break;
             // the later probe of each pair owns the slot
             FOR_LANES_W(l) { if (inside[l] && rb2[l] != (uint32_t)(uint16_t)pos[l] && (uint32_t)pos[l] > rb2[l]) tab16[h[l]] = (uint16_t)pos[l]; }
         }
         CIMG_STAT(g_emu_windows);
-        if (~in_mask) return true;                                       // the window that saw the end of the plane
+        if (~in_mask) { verdict = true; break; }                         // the window that saw the end of the plane
     }
-    return false;
+    return verdict;
 }
 
 // Bit-exact LZ4_compress_fast(in, out, n, cap, accel) in limited-output mode, byU16 table, by one wave.
