@@ -24,6 +24,7 @@ EXPORTS = (
     "cimg_engine_synchronize", "cimg_engine_lock", "cimg_engine_unlock", "cimg_engine_stream", "cimg_compress_batch_device",
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host", "cimg_decompress_batch_host_sized",
     "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
+    "cimg_deinterleave_device", "cimg_compress_batch_host_interleaved_begin",
     "cimg_compress_batch_device_begin", "cimg_compress_batch_device_fetch", "cimg_decompress_batch_device_begin", "cimg_decompress_batch_device_fetch",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
@@ -85,6 +86,8 @@ def load():
     L.cimg_engine_stream.restype = vp
     L.cimg_compress_batch_device.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_decompress_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_deinterleave_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int64]
+    L.cimg_compress_batch_host_interleaved_begin.argtypes = [vp, C.POINTER(CParams), C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp, vp]
     L.cimg_compress_batch_device_begin.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp]
     L.cimg_compress_batch_device_fetch.argtypes = [vp, C.c_int32, vp]
     L.cimg_decompress_batch_device_begin.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
@@ -229,6 +232,10 @@ class Engine:
         if check:
             self._check(rc)
         return status
+
+    def deinterleave_device(self, d_interleaved, nchannels, typesize, npixels, d_planar, plane_stride):
+        """interleaved pixels -> one plane per channel (plane c at d_planar + c * plane_stride), enqueued on the engine's stream"""
+        self._check(load().cimg_deinterleave_device(self.handle, d_interleaved, nchannels, typesize, npixels, d_planar, plane_stride))
 
     # the same in two steps (include/cimg_hip.h): the kernels of one compress and one decompress batch may be in flight together
     def compress_device_begin(self, p, d_raw, raw_off, nbytes, d_comp, comp_off, destsize):

@@ -14,6 +14,7 @@
 
 #include "plan.h"
 #include "assemble_kernel.h"
+#include "deinterleave_kernel.h"
 #include "../../include/cimg_hip.h"
 
 using namespace cimg;
@@ -51,6 +52,13 @@ extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     (void)a;
     encode_gang<CODEC_BLOSCLZ>(lds);
+}
+
+// interleaved pixels -> planes, one wave per 16 KiB tile (deinterleave_kernel.h)
+extern "C" __global__ __launch_bounds__(64) void cimg_deinterleave(DeinterleaveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    deinterleave_wave(a, lds, (int64_t)blockIdx.x);
 }
 
 extern "C" __global__ __launch_bounds__(64) void cimg_layout_chunks(AssembleArgs a)
@@ -166,7 +174,7 @@ struct cimg_engine {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done = nullptr;
     int64_t host_group_bytes = getenv("CIMG_HOST_GROUP_MIB") ? atoll(getenv("CIMG_HOST_GROUP_MIB")) << 20 : 16ll << 20;   // measured: 8 / 16 / 32 / 64 MiB -> 45.9 / 46.6 / 44.3 / 39.0 GB/s
-    DevBuf descs_enc, descs_dec, recs, layout, scratch, stage_raw, stage_comp, dbg, queue;
+    DevBuf descs_enc, descs_dec, recs, layout, scratch, stage_raw, stage_comp, stage_il, dbg, queue;
     // chunk descriptors last uploaded for encode / decode: a batch with the same geometry as the previous one
     // (the steady state of an image pipeline) skips the upload
     std::vector<uint8_t> shadow_enc, shadow_dec;
@@ -210,8 +218,8 @@ struct cimg_engine {
     std::vector<EventPair> pending[CIMG_K_COUNT];
     std::vector<EventPair> pending_extra;   // late general decode launches: time counts towards CIMG_K_DECODE, launches do not
     std::vector<EventPair> free_events;
-    double total_ms[CIMG_K_COUNT] = {0, 0, 0, 0};
-    int64_t launches[CIMG_K_COUNT] = {0, 0, 0, 0};
+    double total_ms[CIMG_K_COUNT] = {};
+    int64_t launches[CIMG_K_COUNT] = {};
     std::string err;
     // a decode batch between decompress_launch() and decompress_finish()
     struct DecodeFlight {
@@ -348,6 +356,7 @@ const char* cimg_kernel_name(int k)
     case CIMG_K_LAYOUT: return "cimg_layout_chunks";
     case CIMG_K_EMIT: return "cimg_emit_blocks";
     case CIMG_K_DECODE: return "cimg_decode_blocks";
+    case CIMG_K_DEINTERLEAVE: return "cimg_deinterleave";
     default: return "?";
     }
 }
@@ -410,7 +419,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->dbg, &e->queue, &e->done})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_descs_dec, &e->h_out, &e->h_dec})
         if (b->p) (void)hipHostFree(b->p);
@@ -947,6 +956,69 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
     e->fetch_off.clear();
     if (nchunks <= 0) return 0;
     return compress_host_pipeline(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes, nullptr, nullptr);
+}
+
+// ---- interleaved pixels -> planes --------------------------------------------------------------------------------------
+static int deinterleave_launch(cimg_engine* e, const void* d_interleaved, int32_t nch, int32_t ts, int64_t npixels, void* d_planar, int64_t plane_stride)
+{
+    if (!d_interleaved || !d_planar) return e->fail(ERR_INVALID_PARAM, "null argument");
+    if (nch < 1 || nch > 4096 || (ts != 1 && ts != 2 && ts != 4 && ts != 8)) return e->fail(ERR_INVALID_PARAM, "deinterleave: %d channels of %d-byte elements are not supported", nch, ts);
+    if (npixels < 0 || (plane_stride & 15) || plane_stride < npixels * ts) return e->fail(ERR_INVALID_PARAM, "deinterleave: the plane stride must be a multiple of 16 and hold a plane");
+    if ((((uintptr_t)d_interleaved) | ((uintptr_t)d_planar)) & 15) return e->fail(ERR_INVALID_PARAM, "deinterleave: buffers must be 16-byte aligned");
+    if (nch * ts * 16 > 16384) return e->fail(ERR_INVALID_PARAM, "deinterleave: %d channels of %d bytes do not fit a tile", nch, ts);
+    if (npixels == 0) return 0;
+    const int tile = deinterleave_tile_pixels(nch, ts);
+    const int64_t tiles = (npixels + tile - 1) / tile;
+    if (tiles > 0x7fffffff) return e->fail(ERR_INVALID_PARAM, "deinterleave: too many pixels for one call");
+    const int lds = deinterleave_lds_bytes(nch, ts);
+    DeinterleaveArgs a{(const uint8_t*)d_interleaved, (uint8_t*)d_planar, plane_stride, npixels, nch, ts, tile, lds};
+    return e->launch(CIMG_K_DEINTERLEAVE, cimg_deinterleave, a, (int)tiles, 64, lds);
+}
+
+int cimg_deinterleave_device(cimg_engine* e, const void* d_interleaved, int32_t nchannels, int32_t typesize, int64_t npixels,
+                             void* d_planar, int64_t plane_stride)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    (void)hipSetDevice(e->device);
+    e->begin_batch(0);
+    return deinterleave_launch(e, d_interleaved, nchannels, typesize, npixels, d_planar, plane_stride);
+}
+
+int cimg_compress_batch_host_interleaved_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchannels, int64_t npixels,
+                                               const void* h_interleaved, int32_t nchunks, const int64_t* raw_off,
+                                               const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    e->fetch_off.clear();
+    if (nchunks <= 0) return 0;
+    if (!p || !h_interleaved || !raw_off || !nbytes || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
+    (void)hipSetDevice(e->device);
+    const int ts = p->typesize;
+    if (nchannels < 1 || npixels <= 0 || (ts != 1 && ts != 2 && ts != 4 && ts != 8)) return e->fail(ERR_INVALID_PARAM, "interleaved batch: %d channels of %d-byte elements are not supported", nchannels, ts);
+    const int64_t plane_stride = (npixels * ts + 15) & ~15ll;
+    const int64_t planar_bytes = plane_stride * nchannels;
+    std::vector<int64_t> d_comp_off((size_t)nchunks);
+    int64_t comp_total = 0;
+    for (int i = 0; i < nchunks; i++) {
+        if (nbytes[i] < 0 || destsize[i] < 0 || raw_off[i] < 0 || raw_off[i] + nbytes[i] > planar_bytes) return e->fail(ERR_INVALID_PARAM, "interleaved batch: chunk %d lies outside the planes", i);
+        d_comp_off[(size_t)i] = comp_total;
+        comp_total += ((int64_t)destsize[i] + 63) & ~63ll;
+    }
+    int rc;
+    const size_t il_bytes = (size_t)npixels * (size_t)nchannels * (size_t)ts;
+    if ((rc = e->reserve(e->stage_il, il_bytes + 64))) return rc;
+    if ((rc = e->reserve(e->stage_raw, (size_t)planar_bytes + 64))) return rc;
+    if ((rc = e->reserve(e->stage_comp, (size_t)comp_total + 64))) return rc;
+    // upload once, split on the device, compress from there: everything on the engine's stream, in order
+    if ((rc = e->hip(hipMemcpyAsync(e->stage_il.p, h_interleaved, il_bytes, hipMemcpyHostToDevice, e->stream), "interleaved pixels H2D"))) return rc;
+    e->begin_batch(0);
+    if ((rc = deinterleave_launch(e, e->stage_il.p, nchannels, ts, npixels, e->stage_raw.p, plane_stride))) { (void)hipStreamSynchronize(e->stream); return rc; }
+    rc = compress_launch(e, p, nchunks, e->stage_raw.p, raw_off, nbytes, e->stage_comp.p, d_comp_off.data(), destsize);
+    const int frc = compress_finish(e, nchunks, cbytes);                // always: nothing may stay in flight on an error path
+    if (rc || frc) return rc ? rc : frc;
+    e->fetch_off = std::move(d_comp_off);
+    e->fetch_len.assign(cbytes, cbytes + nchunks);
+    return 0;
 }
 
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp, const int64_t* comp_off)

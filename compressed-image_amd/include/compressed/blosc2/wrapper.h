@@ -264,6 +264,58 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 				return out;
 			}
 
+			// The same for pixels that arrive INTERLEAVED (R G B A R G B A ...) in host memory: uploaded once, split into planes on
+			// the device (the reference's image_algo::deinterleave, a host loop between reading and compressing, image.h:1880),
+			// compressed from there.  A piece names its bytes in the PLANAR layout: channel c occupies
+			// [c * plane_stride, c * plane_stride + npixels * typesize), plane_stride = that size rounded up to 16.
+			struct planar_piece { size_t offset; size_t nbytes; };
+			inline size_t planar_stride(size_t npixels, size_t typesize) { return (npixels * typesize + 15) & ~size_t{ 15 }; }
+			inline std::vector<byte_buffer> compress_interleaved(context_raw_ptr cctx, const std::byte* interleaved, size_t nchannels, size_t npixels,
+				const std::vector<planar_piece>& pieces, size_t nominal_chunk_bytes)
+			{
+				std::vector<byte_buffer> out(pieces.size());
+				if (pieces.empty()) return out;
+				cimg_cparams cp;
+				int rc = cimg_context_cparams(cctx, &cp);
+				if (rc < 0) throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc));
+				const size_t n = pieces.size();
+				std::vector<int64_t> raw_off(n), comp_off(n);
+				std::vector<int32_t> nbytes(n), destsize(n), cbytes(n);
+				for (size_t i = 0; i < n; ++i)
+				{
+					if (pieces[i].nbytes > static_cast<size_t>(BLOSC2_MAX_BUFFERSIZE))
+						throw std::out_of_range(detail::text("Blosc2 chunk size may not exceed numeric limit of int32_t, got ", pieces[i].nbytes));
+					raw_off[i] = static_cast<int64_t>(pieces[i].offset);
+					nbytes[i] = static_cast<int32_t>(pieces[i].nbytes);
+					destsize[i] = static_cast<int32_t>(min_compressed_size(nominal_chunk_bytes));
+				}
+				struct engine_guard
+				{
+					cimg_engine* e;
+					explicit engine_guard(cimg_engine* e_) : e(e_) { cimg_engine_lock(e); }
+					~engine_guard() { cimg_engine_unlock(e); }
+				} pair_lock(engine());
+				rc = cimg_compress_batch_host_interleaved_begin(engine(), &cp, static_cast<int32_t>(nchannels), static_cast<int64_t>(npixels), interleaved,
+					static_cast<int32_t>(n), raw_off.data(), nbytes.data(), destsize.data(), cbytes.data());
+				if (rc < 0)
+					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
+				size_t total = 0;
+				for (size_t i = 0; i < n; ++i)
+				{
+					if (cbytes[i] <= 0)
+						throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", cbytes[i]));
+					comp_off[i] = static_cast<int64_t>(total);
+					total += (static_cast<size_t>(cbytes[i]) + 63) & ~size_t{ 63 };
+				}
+				std::shared_ptr<std::byte> arena = NAMESPACE_COMPRESSED_IMAGE::detail::pinned_pool::get().arena(total);
+				rc = cimg_compress_batch_host_fetch(engine(), static_cast<int32_t>(n), arena.get(), comp_off.data());
+				if (rc < 0)
+					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
+				for (size_t i = 0; i < n; ++i)
+					out[i] = byte_buffer(arena, arena.get() + comp_off[i], static_cast<size_t>(cbytes[i]));
+				return out;
+			}
+
 			// one chunk -> its pixels; chunk_bytes = what the chunk buffer really holds (0: unknown, trust the header)
 			struct target { const std::byte* chunk; std::byte* out; size_t capacity; size_t chunk_bytes = 0; };
 

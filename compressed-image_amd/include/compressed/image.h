@@ -4,7 +4,8 @@
 //
 // Construction from planar pixels and get_decompressed() batch ACROSS channels: all chunks of all
 // channels go to the MI355X engine in one call (the reference loops channels serially, image.h:119-159).
-// Out of scope in this build: every read() overload and read_oiio_metadata (OpenImageIO is absent) and
+// Out of scope in this build: every read() overload and read_oiio_metadata (OpenImageIO is absent; what the read path does
+// with the scanlines once it has them -- deinterleave, compress -- is image::from_interleaved) and
 // JSON metadata (nlohmann-json is absent; metadata is an ordered string map here).
 #pragma once
 #include <cstddef>
@@ -75,6 +76,43 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			enums::codec compression_codec = enums::codec::lz4, size_t compression_level = 9,
 			size_t block_size = s_default_blocksize, size_t chunk_size = s_default_chunksize)
 			: image(as_spans(channels), width, height, std::move(channel_names), compression_codec, compression_level, block_size, chunk_size) {}
+
+		/// Compress channels that arrive INTERLEAVED (R G B A R G B A ..., what an image reader hands out per block of
+		/// scanlines; the reference's read path deinterleaves them on the host before compressing, image.h:1555-1880 with
+		/// image_algo::deinterleave at :1880).  Not a constructor of the reference -- its read path is tied to OpenImageIO --
+		/// but the same work: the interleaved pixels are uploaded once, split into planes on the device and compressed
+		/// from there, all channels in one engine call.
+		static image from_interleaved(std::span<const T> interleaved, size_t width, size_t height, size_t nchannels, std::vector<std::string> channel_names = {},
+			enums::codec compression_codec = enums::codec::lz4, size_t compression_level = 9,
+			size_t block_size = s_default_blocksize, size_t chunk_size = s_default_chunksize)
+		{
+			if (nchannels == 0 || interleaved.size() != width * height * nchannels)
+				throw std::runtime_error(detail::text("Invalid interleaved data passed. Expected its size to match up to width * height * channels (", width, " * ", height,
+					" * ", nchannels, "). Instead received ", interleaved.size()));
+			image out;
+			out.m_Width = width; out.m_Height = height;
+			out.adopt_names(channel_names, nchannels);
+			const uint8_t level = util::ensure_compression_level(compression_level);
+			const size_t aligned = util::align_chunk_to_scanlines_bytes<T>(width, chunk_size);
+			auto cctx = blosc2::create_compression_context<T>(1, compression_codec, level, block_size);
+			const size_t npixels = width * height, total = npixels * sizeof(T);
+			const size_t stride = blosc2::batch::planar_stride(npixels, sizeof(T));
+			std::vector<blosc2::batch::planar_piece> pieces;
+			std::vector<size_t> first(nchannels + 1, 0);
+			for (size_t ch = 0; ch < nchannels; ++ch)
+			{
+				for (size_t off = 0; off < total; off += aligned) pieces.push_back({ ch * stride + off, std::min(aligned, total - off) });
+				first[ch + 1] = pieces.size();
+			}
+			auto chunks = blosc2::batch::compress_interleaved(cctx.get(), reinterpret_cast<const std::byte*>(interleaved.data()), nchannels, npixels, pieces, aligned);
+			for (size_t ch = 0; ch < nchannels; ++ch)
+			{
+				blosc2::schunk<T> table(block_size, aligned);
+				for (size_t i = first[ch]; i < first[ch + 1]; ++i) table.append_chunk(std::move(chunks[i]));
+				out.m_Channels.push_back(compressed::channel<T>(blosc2::schunk_var<T>(std::move(table)), width, height, compression_codec, level));
+			}
+			return out;
+		}
 
 		/// Adopt already compressed channels.
 		image(std::vector<compressed::channel<T>> channels, size_t width, size_t height, std::vector<std::string> channel_names = {})

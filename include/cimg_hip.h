@@ -87,6 +87,23 @@ int cimg_decompress_batch_device_begin(cimg_engine* e, int32_t nchunks,
                                        void* d_raw, const int64_t* raw_off);
 int cimg_decompress_batch_device_fetch(cimg_engine* e, int32_t* status);
 
+/* ---- interleaved pixels -> planes (reference: image_algo::deinterleave, compressed/image_algo.h:84-111, the step between
+ * reading scanlines and compressing them in the read path, image.h:1880) -------------------------------------------
+ * d_interleaved holds npixels * nchannels elements of `typesize` bytes (R G B A R G B A ...); channel c comes out as
+ * npixels elements at d_planar + c * plane_stride.  plane_stride is in bytes, a multiple of 16, at least npixels * typesize;
+ * both buffers are 16-byte aligned device memory.  typesize is 1, 2, 4 or 8.  Returns when the kernel is enqueued on the
+ * engine's stream (later calls on the same engine see its result). */
+int cimg_deinterleave_device(cimg_engine* e, const void* d_interleaved, int32_t nchannels, int32_t typesize, int64_t npixels,
+                             void* d_planar, int64_t plane_stride);
+/* The producer path in one call: interleaved scanlines in HOST memory are uploaded once, split into planes on the device
+ * and compressed from there.  Chunk i covers nbytes[i] bytes at offset raw_off[i] of the PLANAR layout, in which channel c
+ * occupies [c * plane_stride, c * plane_stride + npixels * typesize) with plane_stride = npixels * typesize rounded up to
+ * 16.  Otherwise as cimg_compress_batch_host_begin: the chunks stay on the device, cbytes[] comes back, and
+ * cimg_compress_batch_host_fetch delivers them. */
+int cimg_compress_batch_host_interleaved_begin(cimg_engine* e, const cimg_cparams* p, int32_t nchannels, int64_t npixels,
+                                               const void* h_interleaved, int32_t nchunks, const int64_t* raw_off,
+                                               const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes);
+
 /* ---- host-resident batches (H2D + kernels + D2H inside) ------------------------------------------ */
 int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
                              const void* h_raw, const int64_t* raw_off, const int32_t* nbytes,
@@ -137,7 +154,7 @@ void* cimg_host_malloc(size_t bytes);
 void  cimg_host_free(void* p);
 
 /* ---- kernel timing (HIP events on the engine's stream) ------------------------------------------- */
-enum { CIMG_K_ENCODE = 0, CIMG_K_LAYOUT = 1, CIMG_K_EMIT = 2, CIMG_K_DECODE = 3, CIMG_K_COUNT = 4 };
+enum { CIMG_K_ENCODE = 0, CIMG_K_LAYOUT = 1, CIMG_K_EMIT = 2, CIMG_K_DECODE = 3, CIMG_K_DEINTERLEAVE = 4, CIMG_K_COUNT = 5 };
 /* on = 0: off; on = n > 0: the kernels of every n-th batch call are bracketed by events (1 = every call).  Each
  * event record costs about 5 us of stream time, so a throughput run samples (bench.py: every 4th batch). */
 void cimg_engine_enable_timing(cimg_engine* e, int on);

@@ -155,3 +155,17 @@ def decompress_batch(chunks, nbytes_list, blocksize_list, misalign=0):
     status = np.zeros(n, np.int32)
     rc = lib().emu_decompress_batch(n, _p(comp), _p(comp_off), _p(nb), _p(bs), _p(raw), _p(raw_off), _p(status))
     return rc, status.tolist(), [raw[raw_off[i]:raw_off[i] + nb[i]].copy() for i in range(n)]
+
+
+def deinterleave(interleaved, nchannels, typesize):
+    """interleaved: uint8 array of npixels * nchannels * typesize bytes.  Returns (nchannels, npixels * typesize) uint8 planes."""
+    src = _u8(interleaved)
+    npixels = src.size // (nchannels * typesize)
+    stride = (npixels * typesize + 15) & ~15
+    dst = np.full(max(stride * nchannels, 16), 0xEE, np.uint8)
+    L = lib()
+    L.emu_deinterleave.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int64]
+    rc = L.emu_deinterleave(_p(src), nchannels, typesize, npixels, _p(dst), stride)
+    if rc < 0:
+        raise ValueError("emu_deinterleave rejected the arguments (%d)" % rc)
+    return np.stack([dst[c * stride:c * stride + npixels * typesize] for c in range(nchannels)]) if npixels else np.zeros((nchannels, 0), np.uint8)

@@ -17,6 +17,7 @@
 
 #include "compressed/channel.h"
 #include "compressed/image.h"
+#include "compressed/image_algo.h"
 #include "compressed/ranges.h"
 #include "compressed/containers/chunk_span.h"
 
@@ -280,6 +281,48 @@ static void zip_cases()
 	CHECK(a[0] == 0 && a[2] == 0 && a[3] == 4);                   // elements are references
 }
 
+// interleave / deinterleave on the host (image_algo.h) and the producer path image::from_interleaved: interleaved pixels
+// are uploaded once, split into planes on the device, compressed from there -- pixels AND chunk bytes equal those of the
+// planar constructor
+template <typename T> static void interleaved_cases()
+{
+	const size_t w = 67, h = 31, n = 3;                                   // odd sizes: ragged tiles, a short last chunk
+	std::vector<std::vector<T>> planes(n, std::vector<T>(w * h));
+	for (size_t c = 0; c < n; ++c)
+		for (size_t i = 0; i < w * h; ++i) planes[c][i] = static_cast<T>((i / 9) * (c + 2) + c * 40 + (i % 3));
+	std::vector<T> mixed(w * h * n);
+	{
+		std::vector<std::span<const T>> in;
+		for (auto& p : planes) in.push_back(std::span<const T>(p));
+		image_algo::interleave<T>(std::span<T>(mixed), in);
+		for (size_t i = 0; i < w * h; i += 17) for (size_t c = 0; c < n; ++c) CHECK(mixed[i * n + c] == planes[c][i]);
+		std::vector<std::vector<T>> back(n, std::vector<T>(w * h));
+		image_algo::deinterleave<T>(std::span<const T>(mixed), back);
+		CHECK(back == planes);
+		std::vector<T> small(5);
+		CHECK(throws<std::invalid_argument>([&] { image_algo::interleave<T>(std::span<T>(small), in); }));
+		std::vector<std::vector<T>> uneven{ std::vector<T>(4), std::vector<T>(5) };
+		CHECK(throws<std::invalid_argument>([&] { image_algo::deinterleave<T>(std::span<const T>(mixed), uneven); }));
+	}
+	const size_t chunk = w * 4 * sizeof(T);                               // 4 scanlines per chunk -> 8 chunks per channel, the last one short
+	auto a = image<T>::from_interleaved(std::span<const T>(mixed), w, h, n, { "R", "G", "B" }, enums::codec::lz4, 9, 256, chunk);
+	image<T> b(planes, w, h, { "R", "G", "B" }, enums::codec::lz4, 9, 256, chunk);
+	CHECK(a.num_channels() == n && a.width() == w && a.height() == h);
+	CHECK(a.get_decompressed() == planes);
+	for (size_t c = 0; c < n; ++c)
+	{
+		auto ra = std::visit([](auto& s) { return s.to_schunk(); }, a.channel(c).chunks());
+		auto rb = std::visit([](auto& s) { return s.to_schunk(); }, b.channel(c).chunks());
+		CHECK(ra->nchunks == rb->nchunks && ra->nchunks == 8);
+		auto csize = [](const uint8_t* ch) { return static_cast<size_t>(ch[12]) | (static_cast<size_t>(ch[13]) << 8) | (static_cast<size_t>(ch[14]) << 16) | (static_cast<size_t>(ch[15]) << 24); };
+		bool same = ra->nchunks == rb->nchunks;
+		for (int64_t k = 0; same && k < ra->nchunks; ++k)
+			same = csize(ra->data[k]) == csize(rb->data[k]) && std::equal(ra->data[k], ra->data[k] + csize(ra->data[k]), rb->data[k]);
+		CHECK(same);
+	}
+	CHECK(throws_any([&] { (void)image<T>::from_interleaved(std::span<const T>(mixed.data(), mixed.size() - 1), w, h, n); }));
+}
+
 // several host threads on the one shared engine: batches are serialised inside the library, results stay correct
 static void thread_cases()
 {
@@ -330,6 +373,9 @@ int main()
 	image_cases<uint8_t>(); image_cases<uint16_t>(); image_cases<uint32_t>(); image_cases<float>();
 	chunk_span_cases();
 	zip_cases();
+	interleaved_cases<uint8_t>();
+	interleaved_cases<uint16_t>();
+	interleaved_cases<float>();
 	thread_cases();
 	std::printf("%d checks, %d failures\n", g_checks, g_failures);
 	return g_failures ? 1 : 0;

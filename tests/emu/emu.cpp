@@ -4,6 +4,7 @@
 // libcimg_hip.so; nothing in the product loads it.
 #define CIMG_EMULATE 1
 #include "plan.h"
+#include "deinterleave_kernel.h"
 #include "assemble_kernel.h"
 #include "blosclz_kernel.h"
 #include <cstdlib>
@@ -137,6 +138,19 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         DecodeBlock* ws[4] = {&w0, &w1, &w2, &w3};
         for (int w = 0; w < 4; w++) ws[w]->phase_a(w);
         for (int w = 0; w < 4; w++) ws[w]->phase_b(w);
+    }
+    return 0;
+}
+
+// interleaved pixels -> planes through the emulated kernel, tile by tile (LDS of exactly the launch size)
+int emu_deinterleave(const uint8_t* src, int nch, int ts, int64_t npixels, uint8_t* dst, int64_t plane_stride)
+{
+    if (nch < 1 || (ts != 1 && ts != 2 && ts != 4 && ts != 8) || (plane_stride & 15) || plane_stride < npixels * ts || nch * ts * 16 > 16384) return -12;
+    const int tile = deinterleave_tile_pixels(nch, ts), lds_bytes = deinterleave_lds_bytes(nch, ts);
+    DeinterleaveArgs a{src, dst, plane_stride, npixels, nch, ts, tile, lds_bytes};
+    for (int64_t t = 0; t * tile < npixels; t++) {
+        std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK, 0xCD);
+        deinterleave_wave(a, lds.data(), t);
     }
     return 0;
 }

@@ -59,6 +59,28 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
     return 0;
 }
 
+extern "C" int emu_deinterleave(const uint8_t* src, int nch, int ts, int64_t npixels, uint8_t* dst, int64_t plane_stride);
+int cimg_deinterleave_device(cimg_engine* e, const void* d_interleaved, int32_t nch, int32_t ts, int64_t npixels, void* d_planar, int64_t plane_stride)
+{
+    LOCK_ENGINE(e);
+    const int rc = emu_deinterleave((const uint8_t*)d_interleaved, nch, ts, npixels, (uint8_t*)d_planar, plane_stride);
+    if (rc < 0) e->err = "deinterleave: invalid arguments";
+    return rc;
+}
+int cimg_compress_batch_host_interleaved_begin(cimg_engine* e, const cimg_cparams* p, int32_t nch, int64_t npixels, const void* h_interleaved,
+                                               int32_t n, const int64_t* raw_off, const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes)
+{
+    LOCK_ENGINE(e);
+    e->off.clear();
+    if (n <= 0) return 0;
+    const int64_t plane_stride = (npixels * p->typesize + 15) & ~15ll;
+    for (int i = 0; i < n; i++) if (raw_off[i] < 0 || raw_off[i] + nbytes[i] > plane_stride * nch) { e->err = "chunk outside the planes"; return -12; }
+    std::vector<uint8_t> planar((size_t)(plane_stride * nch) + 64);
+    const int rc = emu_deinterleave((const uint8_t*)h_interleaved, nch, p->typesize, npixels, planar.data(), plane_stride);
+    if (rc < 0) { e->err = "deinterleave: invalid arguments"; return rc; }
+    return cimg_compress_batch_host_begin(e, p, n, planar.data(), raw_off, nbytes, destsize, cbytes);
+}
+
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t n, void* h_comp, const int64_t* comp_off)
 {
     LOCK_ENGINE(e);
