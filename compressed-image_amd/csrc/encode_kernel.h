@@ -526,6 +526,34 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 break;
             }
             if (stop) break;
+            // ---- the head's third probe, once more ----------------------------------------------------------------
+            // The scalar head only takes hits in front of the first probe that shares a table slot with an earlier one.
+            // Sequential LZ4 goes on: such a probe has the earlier probe's POSITION as its candidate (the slot was just
+            // written) and compares with that probe's four bytes.  The second probe cannot hit that way (v1 != v0 when the
+            // head gets that far), the third can -- and in the high byte planes of an image it usually does: it sits one
+            // byte into a run whose first byte was the second probe (14 of the 15 searches of a tiled plane that the head
+            // gives up on).  Decided here from the ten bytes the head worked on (still in Wn), before any window is laid
+            // out.  (Here and not inside the head loop: there the extra code cost the three-probe path 7 % on data that
+            // never takes it.)
+            if (headed) {
+                const uint32_t w0 = readlane(Wn, 0), w1 = readlane(Wn, 1);
+                const uint32_t v0 = (w0 >> 16) | (w1 << 16), v1 = (w0 >> 24) | (w1 << 8), v2 = w1;
+                const uint32_t h0 = lz4_hash(v0), h1 = lz4_hash(v1), h2 = lz4_hash(v2);
+                const bool e21 = h2 == h1;
+                if ((e21 && v2 == v1) || (!e21 && h2 == h0 && v2 == v0)) {
+                    // the three probes in order (the refill of ip - 2 was written by the head); of two sharing a slot the
+                    // later one owns it
+                    const int p0 = sstart - 1;
+                    FOR_LANES_W(l) { tab16[h0] = (uint16_t)p0; }
+                    FOR_LANES_W(l) { tab16[h1] = (uint16_t)(p0 + 1); }
+                    FOR_LANES_W(l) { tab16[h2] = (uint16_t)(p0 + 2); }
+                    ip = p0 + 2;
+                    mp = e21 ? p0 + 1 : p0;
+                    zero_lit = false;
+                    CIMG_STAT(g_emu_matches);
+                    CIMG_SEQUENCE(false)
+                }
+            }
             const int backpos = pre ? sstart - 3 : 0;             // the "put(ip - 2)" refill after a match
             const bool dense = t0 == 0 && s64 == 64;
             int nv = 64;                                          // valid lanes are a prefix
@@ -565,35 +593,6 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     run_path(v0, readlane(back, 0));
                     CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0);
                     CIMG_SEQUENCE(true)
-                }
-            }
-            // ---- the head's third probe, once more ----------------------------------------------------------------
-            // The scalar head only takes hits in front of the first probe that shares a table slot with an earlier one.
-            // Sequential LZ4 goes on: such a probe has the earlier probe's POSITION as its candidate (the slot was just
-            // written) and compares with that probe's four bytes.  The second probe cannot hit that way (v1 != v0 when the
-            // head gets that far), the third can -- and in the high byte planes of an image it usually does: it sits one
-            // byte into a run whose first byte was the second probe (14 of the 15 searches of a tiled plane that reach
-            // this point).  Lanes 0..2 of the window ARE those probes: decided from registers, no window machinery.
-            // (Here and not inside the head loop: there the extra code cost the three-probe path 7 % on data that never
-            // takes it.)
-            if (headed && nv >= 3) {
-                const uint32_t hh0 = readlane(h, 0), hh1 = readlane(h, 1), hh2 = readlane(h, 2);
-                if (hh2 == hh1 || hh2 == hh0) {
-                    const uint32_t vv0 = readlane(v, 0), vv1 = readlane(v, 1), vv2 = readlane(v, 2);
-                    const bool e21 = hh2 == hh1;
-                    if (e21 ? vv2 == vv1 : vv2 == vv0) {
-                        // the three probes in order (the refill of ip - 2 was written by the head); of two sharing a slot
-                        // the later one owns it
-                        const int p0 = sstart - 1;
-                        FOR_LANES_W(l) { tab16[hh0] = (uint16_t)p0; }
-                        FOR_LANES_W(l) { tab16[hh1] = (uint16_t)(p0 + 1); }
-                        FOR_LANES_W(l) { tab16[hh2] = (uint16_t)(p0 + 2); }
-                        ip = p0 + 2;
-                        mp = e21 ? p0 + 1 : p0;
-                        zero_lit = false;
-                        CIMG_STAT(g_emu_matches);
-                        CIMG_SEQUENCE(false)
-                    }
                 }
             }
             // ---- narrow path ----------------------------------------------------------------------------------
