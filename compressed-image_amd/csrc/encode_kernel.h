@@ -180,16 +180,30 @@ CIMG_DEV bool emit_pending(const uint8_t* in, cimg_global_u8p out, int cap, int&
         }
     }
     if (ballot(ext)) {
-        for (int r = 0;; ++r) {
+        // Length bytes, one byte per lane and round -- for the lanes with at most four of them.  The few with more (a match of
+        // 1035 bytes or longer: 17 for a 4 KiB row of an image) would set the round count for everybody: those are written 64
+        // bytes at a time by the whole wave, one after the other.
+        for (int r = 0; r < 4; ++r) {
             LV<bool> more;
             FOR_LANES(l) {
                 const int lit = P_lit[l], mc = P_mcode[l];
                 const bool act = l < np;
-                if (act && r < le[l]) out[tokpos[l] + 1 + r] = (uint8_t)(r == le[l] - 1 ? lit - 15 - 255 * (le[l] - 1) : 255);
-                if (act && r < me[l]) out[litpos[l] + lit + 2 + r] = (uint8_t)(r == me[l] - 1 ? mc - 15 - 255 * (me[l] - 1) : 255);
-                more[l] = act && (r + 1 < le[l] || r + 1 < me[l]);
+                const int le4 = le[l] <= 4 ? le[l] : 0, me4 = me[l] <= 4 ? me[l] : 0;
+                if (act && r < le4) out[tokpos[l] + 1 + r] = (uint8_t)(r == le4 - 1 ? lit - 15 - 255 * (le4 - 1) : 255);
+                if (act && r < me4) out[litpos[l] + lit + 2 + r] = (uint8_t)(r == me4 - 1 ? mc - 15 - 255 * (me4 - 1) : 255);
+                more[l] = act && (r + 1 < le4 || r + 1 < me4);
             }
             if (!ballot(more)) break;
+        }
+        LV<bool> bigl, bigm;
+        FOR_LANES(l) { bigl[l] = l < np && le[l] > 4; bigm[l] = l < np && me[l] > 4; }
+        for (uint64_t m = ballot(bigl); m; m &= m - 1) {
+            const int k = ctz64(m);
+            emit_len_ext(out, readlane(tokpos, k) + 1, readlane(P_lit, k) - 15);
+        }
+        for (uint64_t m = ballot(bigm); m; m &= m - 1) {
+            const int k = ctz64(m);
+            emit_len_ext(out, readlane(litpos, k) + readlane(P_lit, k) + 2, readlane(P_mcode, k) - 15);
         }
     }
     if (ballot(shortlit)) {
