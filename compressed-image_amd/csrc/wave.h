@@ -305,6 +305,9 @@ CIMG_DEV uint32_t lds_ld32u(const uint8_t* lds, int off)
     return alignbyte(hi, lo, (uint32_t)off & 3u);
 }
 
+// unaligned 32-bit store to LDS: ONE ds_write_b32 on the GPU (gfx950 runs LDS in unaligned access mode)
+CIMG_DEV void lds_st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
 CIMG_HD int imin(int a, int b) { return a < b ? a : b; }
 CIMG_HD int imax(int a, int b) { return a > b ? a : b; }
 
