@@ -44,4 +44,9 @@ share = per_simd[inv]                       # waves on the SIMD of each workgrou
 for k in np.unique(share):
     m = share[wg[:half]] == k
     print("  high-byte plane duration on a SIMD holding %d encode wave(s): mean %.1f us (%d items)" % (k, dur[:half][m].mean(), m.sum()))
+# the tail: which items end last, and how long did they take?
+order = np.argsort(end)[::-1][:12]
+print("  the 12 items that end last: " + ", ".join("%s %d: %.0f us long, ends %.0f" % ("hi" if i < half else "lo", i, dur[i], end[i]) for i in order))
+lo = dur[half:]
+print("  low-byte plane items longer than 20 us: %d of %d (mean of those %.1f us)" % ((lo > 20).sum(), lo.size, lo[lo > 20].mean() if (lo > 20).any() else 0))
 os._exit(0)
