@@ -128,14 +128,27 @@ CIMG_DEV bool blz_emit_pending(const uint8_t* in, cimg_global_u8p out, int cap, 
         }
     }
     if (ballot(longm)) {
-        for (int r = 0;; ++r) {                                    // 255-bytes of long matches, one lane per sequence
+        // 255-bytes of long matches: one lane per sequence and one byte per round for the sequences with at most four of
+        // them; a longer run (a match of 1282 bytes and more: 16 for a 4 KiB row of an image) would set the round count for
+        // everybody and is written 64 bytes at a time by the whole wave instead (encode_kernel.h: emit_pending has the numbers)
+        for (int r = 0; r < 4; ++r) {
             LV<bool> more;
             FOR_LANES(l) {
-                const bool w = longm[l] && r < ext[l] - 1;
+                const int n255 = ext[l] - 1 <= 4 ? ext[l] - 1 : 0;
+                const bool w = longm[l] && r < n255;
                 if (w) out[op + start[l] + lsz[l] + 1 + r] = 255;
-                more[l] = longm[l] && r + 1 < ext[l] - 1;
+                more[l] = longm[l] && r + 1 < n255;
             }
             if (!ballot(more)) break;
+        }
+        LV<bool> big;
+        FOR_LANES(l) { big[l] = longm[l] && ext[l] - 1 > 4; }
+        for (uint64_t m = ballot(big); m; m &= m - 1) {
+            const int k = ctz64(m);
+            const int at = op + readlane(start, k) + readlane(lsz, k) + 1, n255 = readlane(ext, k) - 1;
+            for (int c = 0; c < n255; c += 64) {
+                FOR_LANES_W(l) { if (c + l < n255) out[at + c + l] = 255; }
+            }
         }
     }
     if (ballot(shortlit)) {
