@@ -364,6 +364,9 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
     FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
     uint32_t ctrl = readlane(w, 0) & 31u;
     ip++;
+    // ONE way out of the token loop (`break`, with `bad` set for a damaged stream): returns inside it make the compiler dispatch
+    // every iteration on an exit selector, and an iteration here is one token (encode_kernel.h has the measurement)
+    bool bad = false;
     for (int guard = 0; guard <= csize + 1; ++guard) {
         int k = ip - wbase;
         if (k > 27) {
@@ -380,30 +383,30 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
                     FOR_LANES(l) { stop[l] = (l >= k) & (w[l] != 255); }
                     const int f = ctz64(ballot(stop));
                     if (f < 64) {
-                        if (wbase + f + 1 >= iend) return ERR_DATA;
+                        if (wbase + f + 1 >= iend) { bad = true; break; }
                         len += 255 * (f - k) + (int)readlane(w, f);
                         k = f + 1;
                         break;
                     }
-                    if (wbase + 64 >= iend) return ERR_DATA;
+                    if (wbase + 64 >= iend) { bad = true; break; }
                     len += 255 * (64 - k);
                     wbase += 64; k = 0;
                     FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
                 }
+                if (bad) break;
                 if (k > 56) { wbase += k; k = 0; FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; } }
-            } else if (wbase + k + 1 >= iend) return ERR_DATA;
+            } else if (wbase + k + 1 >= iend) { bad = true; break; }
             const int code = (int)readlane(w, k);
             k++;
             len += 3;
             int ref = op - ofs - code;
             if (code == 255 && ofs == (31 << 8)) {
-                if (wbase + k + 1 >= iend) return ERR_DATA;
+                if (wbase + k + 1 >= iend) { bad = true; break; }
                 ofs = ((int)readlane(w, k) << 8) + (int)readlane(w, k + 1);
                 k += 2;
                 ref = op - ofs - BLZ_MAX_DISTANCE;
             }
-            if (len > oend - op) return ERR_DATA;
-            if (ref - 1 < base) return ERR_DATA;
+            if (len > oend - op || ref - 1 < base) { bad = true; break; }
             ip = wbase + k;
             if (ip >= iend) break;
             ctrl = readlane(w, k);
@@ -427,8 +430,7 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
             op += len;
         } else {
             const int cnt = (int)ctrl + 1;                   // <= 32: the run and the next control byte are in the window
-            if (cnt > oend - op) return ERR_DATA;
-            if (ip + cnt > iend) return ERR_DATA;
+            if (cnt > oend - op || ip + cnt > iend) { bad = true; break; }
             FOR_LANES_W(l) { if (l >= k && l < k + cnt) lds[op + l - k] = (uint8_t)w[l]; }
             op += cnt; ip += cnt;
             if (ip >= iend) break;
@@ -436,7 +438,7 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
             ip++;
         }
     }
-    return op == oend ? 0 : ERR_DATA;
+    return (!bad && op == oend) ? 0 : ERR_DATA;
 }
 
 }  // namespace cimg
