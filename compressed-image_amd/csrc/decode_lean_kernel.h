@@ -138,8 +138,17 @@ struct DecodeLean {
                 LV<uint32_t> tailb;
                 FOR_LANES(l) { tailb[l] = c[lz_pos + imin((units << 4) + l, lz_cs - 1)]; }
                 CIMG_UNROLL
-                for (int k = 0; k < 16; k++) { FOR_LANES(l) { pre[k][l] = ld128u(c + raw_at + 1024 * k + 16 * l); } }
-                prefetched = 1;
+                // eight bytes per lane and load: piece j = stored-plane bytes [512 j + 8 l, + 8), pieces 2 k and 2 k + 1 in pre[k] --
+                // the un-shuffle then writes 16 CONTIGUOUS bytes per lane (a whole KiB per store instruction)
+                for (int k = 0; k < 16; k++) {
+                    FOR_LANES(l) {
+                        uint64_t a, b;
+                        memcpy(&a, c + raw_at + 1024 * k + 8 * l, 8);
+                        memcpy(&b, c + raw_at + 1024 * k + 512 + 8 * l, 8);
+                        pre[k][l].x = (uint32_t)a; pre[k][l].y = (uint32_t)(a >> 32); pre[k][l].z = (uint32_t)b; pre[k][l].w = (uint32_t)(b >> 32);
+                    }
+                }
+                prefetched = 2;
                 CIMG_UNROLL
                 for (int k = 0; k < 4; k++) { FOR_LANES(l) { if (64 * k + l < units) st128a(lds + park + 16 * (64 * k + l), t[k][l]); } }
                 FOR_LANES(l) { if ((units << 4) + l < lz_cs) lds[park + (units << 4) + l] = (uint8_t)tailb[l]; }
@@ -185,6 +194,28 @@ struct DecodeLean {
         if (prefetched) {
             // lane l, piece k: plane bytes [1024 k + 16 l, + 16) of both planes -> 32 contiguous pixels bytes
             // (pair mode: wave w holds pieces 8 w .. 8 w + 7 in pre[0 .. 7])
+            if (prefetched == 2) {
+                // one-wave launch: piece j of both planes -> output bytes [1024 j + 16 l, + 16)
+                CIMG_UNROLL
+                for (int k = 0; k < 16; k++) {
+                    FOR_LANES(l) {
+                        CIMG_UNROLL
+                        for (int half = 0; half < 2; half++) {
+                            const int off8 = 1024 * k + 512 * half + 8 * l;
+                            const uint32_t x0 = *reinterpret_cast<const uint32_t*>(lds + off8), x1 = *reinterpret_cast<const uint32_t*>(lds + off8 + 4);
+                            const uint32_t p0 = half ? pre[k][l].z : pre[k][l].x, p1 = half ? pre[k][l].w : pre[k][l].y;
+                            const uint32_t lo0 = lz_plane == 0 ? x0 : p0, lo1 = lz_plane == 0 ? x1 : p1;      // plane 0 = low bytes
+                            const uint32_t hi0 = lz_plane == 0 ? p0 : x0, hi1 = lz_plane == 0 ? p1 : x1;
+                            u128 o;
+                            o.x = byte_perm(hi0, lo0, 0x05010400u); o.y = byte_perm(hi0, lo0, 0x07030602u);
+                            o.z = byte_perm(hi1, lo1, 0x05010400u); o.w = byte_perm(hi1, lo1, 0x07030602u);
+                            st128u(out + 2 * off8, o);
+                        }
+                    }
+                }
+                if (wave == 0) { FOR_LANES_W(l) { a.done[b] = a.gen; } }
+                return;
+            }
             CIMG_UNROLL
             for (int k = 0; k < 16; k++) {
                 if (pair_mode && k >= 8) break;
