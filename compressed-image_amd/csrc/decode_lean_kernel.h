@@ -64,6 +64,26 @@ struct DecodeLean {
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) return;
         int pos = bstart, coded = 0;
+        // Speculation.  The usual image block stores its low byte plane raw and codes the high one: then the stored plane starts
+        // at bstart + 4 and the coded bytes at bstart + 4 + neblock + 4, and both are requested NOW, together with the size
+        // words, instead of two dependent HBM round trips later (the walk is five of them).  Everything requested lies inside
+        // the chunk; a guess that does not hold costs the loads.
+        const int spec_raw = bstart + 4, spec_lz = bstart + 8 + neblock;
+        const bool spec = nwaves == 1 && !pair_mode && ts == 2 && neblock == 16384 && cbytes - spec_lz >= 4096 + 16;
+        LV<u128> st[4];
+        if (spec) {
+            CIMG_UNROLL
+            for (int k = 0; k < 4; k++) { FOR_LANES(l) { st[k][l] = ld128u(c + spec_lz + 16 * (64 * k + l)); } }
+            CIMG_UNROLL
+            for (int k = 0; k < 16; k++) {
+                FOR_LANES(l) {
+                    uint64_t qa, qb;
+                    memcpy(&qa, c + spec_raw + 1024 * k + 8 * l, 8);
+                    memcpy(&qb, c + spec_raw + 1024 * k + 512 + 8 * l, 8);
+                    pre[k][l].x = (uint32_t)qa; pre[k][l].y = (uint32_t)(qa >> 32); pre[k][l].z = (uint32_t)qb; pre[k][l].w = (uint32_t)(qb >> 32);
+                }
+            }
+        }
         CIMG_UNROLL
         for (int s = 0; s < 4; s++) {                                         // fixed trip count: kind[] / at[] stay in registers
             if (s >= ts) continue;
@@ -129,7 +149,14 @@ struct DecodeLean {
         if (coded == 1 && wave == lzwave) {
             const int park = rs - round16(lz_cs);
             debug_stamp(a.dbg, b, 1);                                             // header walk done
-            if (want_pre && lz_cs <= 4096) {
+            if (want_pre && lz_cs <= 4096 && spec && raw_at == spec_raw && lz_pos == spec_lz) {
+                // the guess held: coded bytes and stored plane are on their way (or here) already; whole 16-byte units go to LDS,
+                // the last one with up to 15 bytes the decoder never looks at (the parking area is round16(lz_cs) long)
+                const int units16 = (lz_cs + 15) >> 4;
+                prefetched = 2;
+                CIMG_UNROLL
+                for (int k = 0; k < 4; k++) { FOR_LANES(l) { if (64 * k + l < units16) st128a(lds + park + 16 * (64 * k + l), st[k][l]); } }
+            } else if (want_pre && lz_cs <= 4096) {
                 // coded bytes first, stored plane behind them: the wait for the coded bytes leaves the 16 plane loads in flight
                 const int units = lz_cs >> 4;
                 LV<u128> t[4];
