@@ -52,8 +52,9 @@ struct EncodeArgs {
     uint64_t* dbg;            // diagnostics only: per-item time stamps (nullptr in production)
     uint32_t* queue;          // work-queue head, zeroed before the launch
     int32_t uniform_nblocks;  // > 0: every chunk has this many blocks
-    int32_t block_items;      // 1 (split launch only): a work item is a whole BLOCK -- read from HBM once, its byte planes
-                              // encoded one after the other by the same wave (the planes that wait sit in registers)
+    int32_t block_items;      // split launch only: the first `block_items` blocks are handed out WHOLE -- read from HBM once, the
+                              // byte planes encoded one after the other by the same wave (the planes that wait sit in registers);
+                              // the blocks behind them plane by plane
 };
 
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
@@ -67,10 +68,13 @@ inline int encode_lds_bytes(int stream_bytes, int compcode = CODEC_LZ4)
 // workgroups on CUs round-robin, not first-free, so the launch is a set of persistent workgroups that
 // pull items from a queue.  Split launch: item i is plane (spb-1 - i / total_blocks) of block
 // i % total_blocks -- most significant byte planes (smooth, many matches, slow) first, noisy low planes
-// last (longest-processing-time-first).  Unsplit launch: item i is block i.
-CIMG_HD int encode_items(int total_blocks, int streams_per_block, bool split, bool block_items = false)
+// last (longest-processing-time-first).  Unsplit launch: item i is block i.  A split launch may hand the first
+// `whole_blocks` blocks out whole (one item each, in front of the plane items of the rest): a block read once instead of once
+// per plane, at the price of a coarser item -- which is why only the rounds that every chain takes anyway are dealt that way
+// and the last, partial round stays plane by plane (engine.hip).
+CIMG_HD int encode_items(int total_blocks, int streams_per_block, bool split, int whole_blocks = 0)
 {
-    return (split && !block_items) ? total_blocks * streams_per_block : total_blocks;
+    return split ? whole_blocks + (total_blocks - whole_blocks) * streams_per_block : total_blocks;
 }
 // A split launch can hand out whole blocks when every full block is the standard 32 KiB of a 2- or 4-byte type, byte
 // shuffled: then the planes that wait for their turn fit in registers (16 KiB / 24 KiB = 64 / 96 VGPRs).
@@ -1028,7 +1032,7 @@ struct EncodeStream {
         uint32_t* queue;
         {
             const auto a = fresh(ap);
-            items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0, a->block_items != 0);
+            items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0, a->block_items);
             queue = a->queue;
         }
         // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
@@ -1045,12 +1049,13 @@ struct EncodeStream {
     // block and stream of a work item (encode_items)
     CIMG_DEV static void item_place(kernarg_ptr<EncodeArgs> a, int item, int& b, int& s)
     {
-        if (a->want_split && !a->block_items) {
-            const int tb = a->total_blocks;
-            b = item % tb;
-            s = a->p.streams_per_block - 1 - item / tb;
-        } else {
+        const int whole = a->want_split ? a->block_items : a->total_blocks;
+        if (item < whole) {
             b = item; s = 0;
+        } else {
+            const int rest = a->total_blocks - whole, idx = item - whole;
+            b = whole + idx % rest;
+            s = a->p.streams_per_block - 1 - idx / rest;
         }
     }
 
@@ -1105,7 +1110,7 @@ struct EncodeStream {
             const uint8_t* src = a->raw + d.raw_off + (int64_t)j * d.blocksize;
             const int filter = a->p.filter;
             const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
-            const bool whole = ns > 1 && a->block_items != 0;            // host guarantees: typesize 2 or 4, 32 KiB, byte shuffle
+            const bool whole = ns > 1 && item < a->block_items;          // host guarantees: typesize 2 or 4, 32 KiB, byte shuffle
             if (whole) { planes = ns; s = ns - 1; }
             out = a->scratch + (int64_t)b * a->p.slot_bytes + (int64_t)s * neblock;
             rec_index = b * a->p.streams_per_block + s;

@@ -206,6 +206,7 @@ struct cimg_engine {
     bool verbose = getenv("CIMG_VERBOSE") != nullptr;
     int enc_wgs_limit = getenv("CIMG_ENC_WGS_PER_CU") ? atoi(getenv("CIMG_ENC_WGS_PER_CU")) : 0;
     int enc_block_items = getenv("CIMG_ENC_BLOCK_ITEMS") ? atoi(getenv("CIMG_ENC_BLOCK_ITEMS")) : -1;   // -1: by batch size
+    int enc_hybrid = getenv("CIMG_ENC_HYBRID") ? atoi(getenv("CIMG_ENC_HYBRID")) : 1;                  // 0: a small batch goes plane by plane throughout
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
@@ -555,11 +556,21 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         // on a small batch the coarser granularity costs more than the second read saves (HBM is a few per cent utilised;
         // measured on 4 x 4096^2 float16 = 3.2 blocks per resident wave: 537 us against 512 us; from 8 rounds on the tail
         // is noise).  CIMG_ENC_BLOCK_ITEMS=1 / 0 forces the choice.
-        bool block_items = split && (e->enc_block_items == 1 || (e->enc_block_items < 0 && plan.total_blocks >= 8 * 5 * e->num_cus));
-        if (block_items)
+        bool block_items_ok = split != 0;
+        if (block_items_ok)
             for (const ChunkDesc& d : plan.descs)
-                if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
-        const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, block_items);
+                if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items_ok = false; break; }
+        // how many of the blocks go out whole: all of them on a large batch; on a small one the rounds every chain takes anyway,
+        // while the last, partial round (where a coarser item would cost a whole extra item on the slowest chain) stays plane
+        // by plane.  configs[1]: 4096 blocks on 1280 chains = 3.2 rounds -> 3072 whole blocks, 1024 plane by plane.
+        int whole_blocks = 0;
+        if (block_items_ok) {
+            const int chains = std::max(1, e->lds_per_cu / std::max(lds_bytes, 1)) * e->num_cus;
+            const double rounds = (double)plan.total_blocks / chains;
+            if (e->enc_block_items == 1 || (e->enc_block_items < 0 && rounds >= 8.0)) whole_blocks = plan.total_blocks;
+            else if (e->enc_block_items < 0 && e->enc_hybrid) whole_blocks = std::min(plan.total_blocks, std::max(0, (int)((rounds - 0.8) * chains)));
+        }
+        const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks);
         uint64_t* dbg = nullptr;
         if (e->stamps && split) {       // diagnostics: 16 uint64 per item (start / end stamps; -DCIMG_PROFILE builds: cycle accounting)
             if ((rc = e->reserve(e->dbg, (size_t)items * 128))) return rc;
@@ -569,7 +580,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         }
         uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
-                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, block_items ? 1 : 0};
+                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : cimg_encode_streams;
         // persistent chains, as many as are resident at once and never more than there are items; ganged into workgroups so

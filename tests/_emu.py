@@ -81,6 +81,12 @@ def set_lean(on):
     lib().emu_set_lean(1 if on else 0)
 
 
+def set_block_items(mode):
+    """0: every work item of the split encode launch is one byte plane; 1: a whole block; 2: the first half of the blocks whole,
+    the rest plane by plane (the mixed queue the engine builds for a small batch)"""
+    lib().emu_set_block_items(int(mode))
+
+
 def lean_blocks():
     """Blocks the lean decode kernel produced since the last call."""
     lib().emu_lean_blocks.restype = C.c_long

@@ -60,7 +60,9 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         if (block_items)
             for (const ChunkDesc& d : plan.descs)
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
-        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, block_items ? 1 : 0};
+        // 1: every block whole; 2: the first half whole, the rest plane by plane (the mixed queue of a small batch)
+        const int whole_blocks = !block_items ? 0 : (g_emu_block_items == 2 ? plan.total_blocks / 2 : plan.total_blocks);
+        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, whole_blocks};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }

@@ -235,3 +235,27 @@ def test_randomized_geometries_against_the_oracle():
             assert rc == 0 and not any(st)
             want = b"".join(raw[sum(sizes[:i]):sum(sizes[:i + 1])].tobytes() for i, c in enumerate(chunks) if len(c))
             assert b"".join(o.tobytes() for o in outs) == want
+
+
+def test_encode_work_item_shapes_give_the_same_bytes():
+    """The split encode launch deals blocks out whole, plane by plane, or -- on a small batch -- the full rounds whole and the
+    last partial round plane by plane (encode_kernel.h: encode_items / item_place).  Whatever the queue looks like, the chunks
+    are the oracle's, for 2- and 4-byte types, lz4 and blosclz, with a leftover block in the batch."""
+    import _oracle as O
+    from cimg import synth
+    try:
+        for dtype, ts in ((np.float16, 2), (np.float32, 4)):
+            raw = synth.tiled_channel(dtype, 1024, 130).view(np.uint8).ravel()
+            sizes = [131072, 131072, raw.size - 262144] if raw.size > 262144 else [131072, raw.size - 131072]
+            for code in (1, 0):
+                want = []
+                off = 0
+                for n in sizes:
+                    want.append(O.compress(O.cparams(ts, compcode=code), raw[off:off + n])[1])
+                    off += n
+                for mode in (0, 1, 2):
+                    E.set_block_items(mode)
+                    rc, cb, chunks = E.compress_batch(E.cparams(ts, compcode=code), raw, sizes, [n + 32 for n in sizes])
+                    assert rc == 0 and chunks == want, (dtype, code, mode)
+    finally:
+        E.set_block_items(1)

@@ -344,7 +344,9 @@ def test_general_decode_kernel_alone_still_covers_every_block():
 @pytest.mark.parametrize("force", ["1", "0"])
 def test_encode_block_items_and_plane_items_give_the_same_bytes(force):
     """The split encode launch hands out whole blocks (each read from HBM once, waiting planes in registers) on large
-    batches and single byte planes on small ones (CIMG_ENC_BLOCK_ITEMS forces either, read when an engine is created):
+    batches, and on small ones for the rounds every chain takes anyway with the last partial round plane by plane
+    (CIMG_ENC_BLOCK_ITEMS forces all / none, read when an engine is created; the mixed queue runs in
+    test_encode_automatic_gang_on_a_batch_that_fills_the_device and in the emulator, tests/test_emu_kernels.py):
     both must produce the oracle's bytes, for lz4 and blosclz, 2- and 4-byte types, with leftover blocks in the batch."""
     os.environ["CIMG_ENC_BLOCK_ITEMS"] = force
     try:
