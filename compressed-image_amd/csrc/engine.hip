@@ -562,13 +562,13 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items_ok = false; break; }
         // how many of the blocks go out whole: all of them on a large batch; on a small one the rounds every chain takes anyway,
         // while the last, partial round (where a coarser item would cost a whole extra item on the slowest chain) stays plane
-        // by plane.  configs[1]: 4096 blocks on 1280 chains = 3.2 rounds -> 3072 whole blocks, 1024 plane by plane.
+        // by plane.  configs[1]: 4096 blocks on 1280 chains = 3.2 rounds -> 3840 whole blocks, 256 plane by plane.
         int whole_blocks = 0;
         if (block_items_ok) {
             const int chains = std::max(1, e->lds_per_cu / std::max(lds_bytes, 1)) * e->num_cus;
             const double rounds = (double)plan.total_blocks / chains;
             if (e->enc_block_items == 1 || (e->enc_block_items < 0 && rounds >= 8.0)) whole_blocks = plan.total_blocks;
-            else if (e->enc_block_items < 0 && e->enc_hybrid) whole_blocks = std::min(plan.total_blocks, std::max(0, (int)((rounds - 0.8) * chains)));
+            else if (e->enc_block_items < 0 && e->enc_hybrid) whole_blocks = std::min(plan.total_blocks, (int)rounds * chains);   // the FULL rounds
         }
         const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks);
         uint64_t* dbg = nullptr;
