@@ -241,6 +241,39 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
 {
     bool verdict = false;                                               // one way out of the loop (see lz4_encode_body)
     for (int t0 = 0; t0 <= n; t0 += 64) {                               // hard bound: a window commits 64 probes
+        // TWO windows per LDS round trip while nothing happens: the second window's slot reads are issued behind the first
+        // window's writes (LDS executes a wave's operations in order), so it sees exactly the table sequential LZ4 would show it.
+        // Anything eventful in either -- two probes of one window sharing a slot included -- puts both back and leaves the
+        // first to the one-window form below.
+        {
+            LV<int> p1, p2;
+            LV<bool> in2;
+            FOR_LANES(l) {
+                const int ta = t0 + l, tb = t0 + 64 + l;
+                int pa = 1 + ta;
+                if (ta > 0) pa = 2 + skip_prefix(s64 + ta - 1) - f64;
+                const int pb = 2 + skip_prefix(s64 + tb - 1) - f64, gb = (s64 + tb - 1) >> 6;
+                p1[l] = pa; p2[l] = pb;
+                in2[l] = pb + gb <= mflimit_p1;                                  // the later window inside means the earlier one is
+            }
+            if (!~ballot(in2)) {
+                LV<uint32_t> v1, v2, h1, h2, o1, o2, r1, r2, c1, c2;
+                FOR_LANES(l) { v1[l] = lds_ld32u(in, p1[l]); v2[l] = lds_ld32u(in, p2[l]); h1[l] = lz4_hash(v1[l]); h2[l] = lz4_hash(v2[l]); }
+                FOR_LANES(l) { o1[l] = tab16[h1[l]]; }
+                FOR_LANES_W(l) { tab16[h1[l]] = (uint16_t)p1[l]; }
+                FOR_LANES(l) { r1[l] = tab16[h1[l]]; }
+                FOR_LANES(l) { o2[l] = tab16[h2[l]]; }
+                FOR_LANES_W(l) { tab16[h2[l]] = (uint16_t)p2[l]; }
+                FOR_LANES(l) { r2[l] = tab16[h2[l]]; c1[l] = lds_ld32u(in, (int)o1[l]); c2[l] = lds_ld32u(in, (int)o2[l]); }
+                LV<bool> eventful;
+                FOR_LANES(l) {
+                    eventful[l] = (r1[l] != (uint32_t)(uint16_t)p1[l]) | (c1[l] == v1[l]) | (r2[l] != (uint32_t)(uint16_t)p2[l]) | (c2[l] == v2[l]);
+                }
+                if (!ballot(eventful)) { CIMG_STAT(g_emu_windows); CIMG_STAT(g_emu_windows); t0 += 64; continue; }
+                FOR_LANES_W(l) { tab16[h2[l]] = (uint16_t)o2[l]; }          // the later window first: it may hold the earlier one's positions
+                FOR_LANES_W(l) { tab16[h1[l]] = (uint16_t)o1[l]; }
+            }
+        }
         LV<int> pos;
         LV<bool> inside;
         FOR_LANES(l) {
