@@ -13,8 +13,10 @@
  *      call here.  Plain pointers and sizes only; no HIP or torch types.
  *
  * All functions return 0 (or a non-negative size) on success and a negative c-blosc2 error code
- * (include/blosc2.h, BLOSC2_ERROR_*) on failure; cimg_last_error() gives the text.  An engine is
- * not thread-safe (the reference's contexts are not either, channel.h:511-513).
+ * (include/blosc2.h, BLOSC2_ERROR_*) on failure; cimg_last_error() gives the text.  Every call takes
+ * the engine's own (recursive) lock, so calls from several threads are serialised, not interleaved;
+ * a _begin / _fetch pair is made one unit by holding cimg_engine_lock() across it.  (The reference's
+ * contexts are not thread-safe at all, channel.h:511-513.)
  */
 #ifndef CIMG_HIP_H
 #define CIMG_HIP_H
