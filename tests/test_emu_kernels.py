@@ -40,6 +40,30 @@ def test_wave_lz4_encoder_matches_liblz4(kat, order):
         E.set_write_order(0)
 
 
+def test_noise_planes_match_the_oracle():
+    """Noise planes go through the no-match walk of the encoder; one in forty has a table slot that three probes of a window
+    share, one in eighty a real four-byte repeat that LZ4 finds -- both hand the plane to the full encoder.  Same verdict, same
+    bytes as the oracle in every write order, also with repeats planted inside the first windows."""
+    rng = np.random.default_rng(77)
+    planes = [rng.integers(0, 256, 16384, dtype=np.uint8) for _ in range(240)]
+    for k in range(40):                                   # near-noise: a few repeats planted, some inside the first windows
+        p = rng.integers(0, 256, 16384, dtype=np.uint8)
+        for _ in range(int(rng.integers(1, 4))):
+            a = int(rng.integers(0, 2000)); b = a + int(rng.integers(4, 400)); n = int(rng.integers(4, 24))
+            p[b:b + n] = p[a:a + n]
+        planes.append(p)
+    try:
+        for order in (0, 1, 2):
+            E.set_write_order(order)
+            for i, p in enumerate(planes):
+                cap = p.size + p.size // 255 + 16 - 1 if i % 3 == 0 else p.size
+                r, out, need = E.lz4_encode(p, cap)
+                ro, oo, no = O.lz4_compress(p, cap, want_need=True)
+                assert r == ro and out == oo and (r <= 0 or need == no), (order, i)
+    finally:
+        E.set_write_order(0)
+
+
 def test_wave_lz4_need_matches_liblz4(kat):
     for key in (k for k in kat.files if k.startswith("need|")):
         _, name, a = key.split("|")

@@ -49,4 +49,15 @@ order = np.argsort(end)[::-1][:12]
 print("  the 12 items that end last: " + ", ".join("%s %d: %.0f us long, ends %.0f" % ("hi" if i < half else "lo", i, dur[i], end[i]) for i in order))
 lo = dur[half:]
 print("  low-byte plane items longer than 20 us: %d of %d (mean of those %.1f us)" % ((lo > 20).sum(), lo.size, lo[lo > 20].mean() if (lo > 20).any() else 0))
+# the long low-byte items: when do they start, on what kind of workgroup, and which stamps are far apart?
+ls, ld = start[half:], dur[half:]
+for a, b in ((0, 250), (250, 270), (270, 280), (280, 290), (290, 400)):
+    m = (ls >= a) & (ls < b)
+    if m.any(): print("  low-byte items starting in [%d, %d) us: %d, duration mean %.1f p50 %.1f p90 %.1f max %.1f" % (a, b, m.sum(), ld[m].mean(), *np.percentile(ld[m], [50, 90]), ld[m].max()))
+long_i = half + np.nonzero(ld > 25)[0]
+if long_i.size:
+    staged = (st[long_i, 5] - st[long_i, 1]) / 100.0 if st.shape[1] > 5 else None
+    print("  long low-byte items: on workgroups that took %s high-byte planes; blocks %s ..." % (np.bincount(hi[wg[long_i]]).tolist(), (long_i[:16] - half).tolist()))
+    for i in long_i[:6]:
+        print("    item %d stamps (us from item start): %s" % (i, [round((int(x) - int(st[i, 1])) / 100.0, 1) if x else None for x in st[i, :16]]))
 os._exit(0)
