@@ -1,0 +1,442 @@
+// zstd_decode.h -- a Zstandard FRAME decoder (RFC 8878), the read side of blosc2's codec format 4.
+//
+// The reference offers enums::codec::zstd (enums.h:18-24, wrapper.h:74-119); c-blosc2 then stores every stream of a block
+// as one complete zstd frame (ZSTD_compressCCtx, no dictionary, no checksum).  Compression with zstd is NOT built here (no
+// zstd encoder can be pinned byte-exactly in this image) -- but chunks the reference wrote with it must
+// still be readable, and decoding is defined by the format alone.  This file is that decoder: plain scalar code, written
+// from the format description, with every table in a caller-provided work area (LDS on the device).  It is the slow path
+// by design: one lane's worth of work per stream (all lanes of the wave execute it redundantly, uniformly), no attempt at
+// the wave-parallel entropy decoding a fast path would need.  Pinned by frames libzstd 1.4.8 produced at levels 1 - 19
+// (tests/golden/zstd_kat.npz, tests/golden/make_zstd_golden.py).
+//
+// Limits (anything else is ERR_CODEC_SUPPORT / ERR_DATA, never an out-of-range access): regenerated size of a frame <= the
+// caller's capacity, literals of one block <= ZSTD_LIT_CAP, no dictionary, window = the frame itself.
+#pragma once
+#include "codec_types.h"
+#include "wave.h"
+
+namespace cimg {
+
+enum : int { ZSTD_LIT_CAP = 65536, ZSTD_HUF_LOG_MAX = 11, ZSTD_FSE_LOG_MAX = 9 };
+
+struct ZstdFseEntry { uint8_t sym, nb; uint16_t base; };
+
+struct ZstdWork {
+    uint8_t huf_sym[1 << ZSTD_HUF_LOG_MAX];
+    uint8_t huf_nb[1 << ZSTD_HUF_LOG_MAX];
+    ZstdFseEntry ll[1 << ZSTD_FSE_LOG_MAX], ml[1 << ZSTD_FSE_LOG_MAX], of[1 << ZSTD_FSE_LOG_MAX], wt[64];
+    int16_t freq[256];
+    uint16_t sdesc[256];
+    uint8_t weights[256];
+    int32_t ll_log, ml_log, of_log, huf_log, have_huf, have_tables;
+    uint8_t* lit;            // literal buffer of ZSTD_LIT_CAP bytes
+};
+
+// ---- bit readers --------------------------------------------------------------------------------------------------
+// bits [off, off + n) of src (LSB-first within bytes), n <= 32; bytes outside [0, size) read as zero
+CIMG_HD uint32_t zstd_bits(const uint8_t* src, int size, int64_t off, int n)
+{
+    if (n <= 0) return 0;
+    uint64_t acc = 0;
+    const int64_t b0 = off >> 3;
+    for (int k = 0; k < 5; k++) {
+        const int64_t b = b0 + k;
+        const uint64_t v = (b >= 0 && b < size) ? src[b] : 0;
+        acc |= v << (8 * k);
+    }
+    return (uint32_t)((acc >> (off & 7)) & ((1ull << n) - 1));
+}
+// backward stream: *off is the bit position just above the next bits; bits below position 0 read as zero
+CIMG_HD uint32_t zstd_rbits(const uint8_t* src, int size, int64_t* off, int n)
+{
+    *off -= n;
+    if (n <= 0) return 0;
+    if (*off >= 0) return zstd_bits(src, size, *off, n);
+    const int64_t miss = -*off;                       // bits that lie below the start of the stream
+    if (miss >= n) return 0;
+    return zstd_bits(src, size, 0, (int)(n - miss)) << miss;
+}
+CIMG_HD int zstd_highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
+
+// ---- FSE ------------------------------------------------------------------------------------------------------------
+// table description at src[0..size): fills w->freq, returns bytes consumed (< 0: error); *log_out = accuracy log
+CIMG_HD int zstd_fse_read_header(const uint8_t* src, int size, int max_log, int max_sym, ZstdWork* w, int* log_out, int* nsym_out)
+{
+    int64_t off = 0;
+    const int log = 5 + (int)zstd_bits(src, size, off, 4);
+    off += 4;
+    if (log > max_log) return ERR_DATA;
+    int remaining = 1 << log, sym = 0;
+    while (remaining > 0 && sym <= max_sym) {
+        const int bits = zstd_highbit((uint32_t)remaining + 1) + 1;
+        int val = (int)zstd_bits(src, size, off, bits);
+        off += bits;
+        const int lower = (1 << (bits - 1)) - 1;
+        const int threshold = (1 << bits) - 1 - (remaining + 1);
+        if ((val & lower) < threshold) { off -= 1; val &= lower; }
+        else if (val > lower) val -= threshold;
+        const int proba = val - 1;
+        remaining -= proba < 0 ? -proba : proba;
+        w->freq[sym++] = (int16_t)proba;
+        if (proba == 0) {
+            int rep = (int)zstd_bits(src, size, off, 2);
+            off += 2;
+            for (;;) {
+                for (int i = 0; i < rep && sym <= max_sym; i++) w->freq[sym++] = 0;
+                if (rep != 3) break;
+                rep = (int)zstd_bits(src, size, off, 2);
+                off += 2;
+            }
+        }
+        if (off > (int64_t)size * 8 + 16) return ERR_DATA;
+    }
+    if (remaining != 0 || sym > max_sym + 1) return ERR_DATA;
+    *log_out = log;
+    *nsym_out = sym;
+    const int used = (int)((off + 7) >> 3);
+    return used > size ? ERR_DATA : used;
+}
+
+CIMG_HD int zstd_fse_build(ZstdFseEntry* t, int log, int nsym, ZstdWork* w)
+{
+    const int size = 1 << log;
+    int high = size;
+    for (int s = 0; s < nsym; s++)
+        if (w->freq[s] == -1) { t[--high].sym = (uint8_t)s; w->sdesc[s] = 1; }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        if (w->freq[s] <= 0) continue;
+        w->sdesc[s] = (uint16_t)w->freq[s];
+        for (int i = 0; i < w->freq[s]; i++) {
+            t[pos].sym = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos >= high);
+        }
+    }
+    if (pos != 0) return ERR_DATA;
+    for (int i = 0; i < size; i++) {
+        const int s = t[i].sym;
+        const int next = w->sdesc[s]++;
+        const int nb = log - zstd_highbit((uint32_t)next);
+        t[i].nb = (uint8_t)nb;
+        t[i].base = (uint16_t)((next << nb) - size);
+    }
+    return 0;
+}
+
+CIMG_HD void zstd_fse_rle(ZstdFseEntry* t, int sym) { t[0].sym = (uint8_t)sym; t[0].nb = 0; t[0].base = 0; }
+
+// predefined distributions (RFC 8878 section 3.1.1.3.2.2)
+CIMG_HD int zstd_default_freq(int which, int i)
+{
+    // which: 0 literal lengths (36 symbols, log 6), 1 offsets (29, log 5), 2 match lengths (53, log 6)
+    if (which == 0) {
+        if (i == 0) return 4;
+        if (i == 1 || i == 25) return 3;
+        if ((i >= 13 && i <= 15) || (i >= 27 && i <= 31)) return 1;
+        if (i >= 32) return -1;
+        return 2;
+    }
+    if (which == 1) {
+        if (i >= 24) return -1;
+        if (i >= 6 && i <= 8) return 2;
+        return 1;
+    }
+    if (i == 0) return 1;
+    if (i == 1) return 4;
+    if (i == 2) return 3;
+    if (i >= 3 && i <= 8) return 2;
+    if (i >= 46) return -1;
+    return 1;
+}
+
+CIMG_HD int zstd_ll_base(int c) { return c < 16 ? c : c < 20 ? 16 + 2 * (c - 16) : c < 22 ? 24 + 4 * (c - 20) : c < 24 ? 32 + 8 * (c - 22) : c == 24 ? 48 : 64 << (c - 25); }
+CIMG_HD int zstd_ll_bits(int c) { return c < 16 ? 0 : c < 20 ? 1 : c < 22 ? 2 : c < 24 ? 3 : c == 24 ? 4 : c - 19; }
+CIMG_HD int zstd_ml_base(int c)
+{
+    if (c < 32) return c + 3;
+    if (c < 36) return 35 + 2 * (c - 32);
+    if (c < 38) return 43 + 4 * (c - 36);
+    if (c < 40) return 51 + 8 * (c - 38);
+    if (c < 42) return 67 + 16 * (c - 40);
+    if (c == 42) return 99;
+    return (128 << (c - 43)) + 3;
+}
+CIMG_HD int zstd_ml_bits(int c) { return c < 32 ? 0 : c < 36 ? 1 : c < 38 ? 2 : c < 40 ? 3 : c < 42 ? 4 : c == 42 ? 5 : c - 36; }
+
+// ---- Huffman ----------------------------------------------------------------------------------------------------------
+// tree description at src: fills the decoding table, returns bytes consumed
+CIMG_HD int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
+{
+    if (size < 1) return ERR_DATA;
+    const int hb = src[0];
+    int n = 0, used;
+    if (hb >= 128) {
+        n = hb - 127;
+        used = 1 + (n + 1) / 2;
+        if (used > size) return ERR_DATA;
+        for (int i = 0; i < n; i++) w->weights[i] = (i & 1) ? (src[1 + i / 2] & 15) : (src[1 + i / 2] >> 4);
+    } else {
+        if (hb == 0 || 1 + hb > size) return ERR_DATA;
+        const uint8_t* f = src + 1;
+        int log = 0, nsym = 0;
+        const int h = zstd_fse_read_header(f, hb, 6, 12, w, &log, &nsym);
+        if (h < 0) return h;
+        int rc = zstd_fse_build(w->wt, log, nsym, w);
+        if (rc < 0) return rc;
+        const uint8_t* bs = f + h;
+        const int bl = hb - h;
+        if (bl < 1 || bs[bl - 1] == 0) return ERR_DATA;
+        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(bs[bl - 1]));
+        const int mask = (1 << log) - 1;
+        int s1 = (int)zstd_rbits(bs, bl, &off, log), s2 = (int)zstd_rbits(bs, bl, &off, log);
+        for (;;) {
+            if (n >= 254) return ERR_DATA;
+            w->weights[n++] = w->wt[s1 & mask].sym;
+            s1 = w->wt[s1 & mask].base + (int)zstd_rbits(bs, bl, &off, w->wt[s1 & mask].nb);
+            if (off < 0) { w->weights[n++] = w->wt[s2 & mask].sym; break; }
+            w->weights[n++] = w->wt[s2 & mask].sym;
+            s2 = w->wt[s2 & mask].base + (int)zstd_rbits(bs, bl, &off, w->wt[s2 & mask].nb);
+            if (off < 0) { w->weights[n++] = w->wt[s1 & mask].sym; break; }
+        }
+        used = 1 + hb;
+    }
+    // the last weight is implied: the sum of 2^(w-1) is a power of two
+    uint32_t sum = 0;
+    for (int i = 0; i < n; i++) { if (w->weights[i] > ZSTD_HUF_LOG_MAX) return ERR_DATA; if (w->weights[i]) sum += 1u << (w->weights[i] - 1); }
+    if (sum == 0) return ERR_DATA;
+    const int maxbits = zstd_highbit(sum) + 1;
+    if (maxbits > ZSTD_HUF_LOG_MAX) return ERR_DATA;
+    const uint32_t left = (1u << maxbits) - sum;
+    if (left & (left - 1)) return ERR_DATA;
+    w->weights[n++] = (uint8_t)(zstd_highbit(left) + 1);
+    // code lengths -> table: longest codes first, symbols in ascending order within a length
+    int rank_count[ZSTD_HUF_LOG_MAX + 2], rank_idx[ZSTD_HUF_LOG_MAX + 2];
+    for (int i = 0; i <= ZSTD_HUF_LOG_MAX + 1; i++) rank_count[i] = 0;
+    for (int i = 0; i < n; i++) { const int b = w->weights[i] ? maxbits + 1 - w->weights[i] : 0; w->weights[i] = (uint8_t)b; rank_count[b]++; }
+    rank_idx[maxbits] = 0;
+    for (int i = maxbits; i >= 1; i--) rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1 << (maxbits - i));
+    if (rank_idx[0] != (1 << maxbits)) return ERR_DATA;
+    for (int i = 0; i < n; i++) {
+        const int b = w->weights[i];
+        if (!b) continue;
+        const int len = 1 << (maxbits - b);
+        for (int k = 0; k < len; k++) { w->huf_sym[rank_idx[b] + k] = (uint8_t)i; w->huf_nb[rank_idx[b] + k] = (uint8_t)b; }
+        rank_idx[b] += len;
+    }
+    w->huf_log = maxbits;
+    w->have_huf = 1;
+    return used;
+}
+
+CIMG_HD int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int count, const ZstdWork* w)
+{
+    if (size < 1 || src[size - 1] == 0) return ERR_DATA;
+    const int log = w->huf_log, mask = (1 << log) - 1;
+    int64_t off = (int64_t)size * 8 - (8 - zstd_highbit(src[size - 1]));
+    int state = (int)zstd_rbits(src, size, &off, log);
+    int n = 0;
+    while (off > -log) {
+        if (n >= count) return ERR_DATA;
+        out[n++] = w->huf_sym[state & mask];
+        const int nb = w->huf_nb[state & mask];
+        state = ((state << nb) + (int)zstd_rbits(src, size, &off, nb)) & mask;
+    }
+    return (off == -log && n == count) ? 0 : ERR_DATA;
+}
+
+// ---- one compressed block ---------------------------------------------------------------------------------------------
+struct ZstdFrameState { int rep[3]; };
+
+CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int dcap, ZstdWork* w, ZstdFrameState* fs)
+{
+    if (size < 1) return ERR_DATA;
+    // ---- literals section
+    const int ltype = src[0] & 3, sf = (src[0] >> 2) & 3;
+    int regen, comp = 0, hdr, streams = 1;
+    if (ltype < 2) {
+        if (sf == 0 || sf == 2) { hdr = 1; regen = src[0] >> 3; }
+        else if (sf == 1) { hdr = 2; if (size < 2) return ERR_DATA; regen = (src[0] >> 4) | (src[1] << 4); }
+        else { hdr = 3; if (size < 3) return ERR_DATA; regen = (src[0] >> 4) | (src[1] << 4) | (src[2] << 12); }
+    } else {
+        if (size < 5) { if (size < 3 || sf >= 2) return ERR_DATA; }
+        const uint64_t v = (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)(size > 3 ? src[3] : 0) << 24) | ((uint64_t)(size > 4 ? src[4] : 0) << 32);
+        if (sf == 0 || sf == 1) { hdr = 3; regen = (int)((v >> 4) & 0x3FF); comp = (int)((v >> 14) & 0x3FF); streams = sf == 0 ? 1 : 4; }
+        else if (sf == 2) { hdr = 4; regen = (int)((v >> 4) & 0x3FFF); comp = (int)((v >> 18) & 0x3FFF); streams = 4; }
+        else { hdr = 5; regen = (int)((v >> 4) & 0x3FFFF); comp = (int)((v >> 22) & 0x3FFFF); streams = 4; }
+    }
+    if (regen > ZSTD_LIT_CAP) return ERR_CODEC_SUPPORT;
+    int pos = hdr;
+    const uint8_t* lit = w->lit;
+    if (ltype == 0) {
+        if (pos + regen > size) return ERR_DATA;
+        lit = src + pos;                                   // raw literals are used where they lie
+        pos += regen;
+    } else if (ltype == 1) {
+        if (pos + 1 > size) return ERR_DATA;
+        for (int i = 0; i < regen; i++) w->lit[i] = src[pos];
+        pos += 1;
+    } else {
+        if (pos + comp > size) return ERR_DATA;
+        const uint8_t* ls = src + pos;
+        int lsz = comp;
+        if (ltype == 2) {
+            const int t = zstd_huf_read_tree(ls, lsz, w);
+            if (t < 0) return t;
+            ls += t; lsz -= t;
+        } else if (!w->have_huf) return ERR_DATA;
+        if (streams == 1) {
+            const int rc = zstd_huf_stream(ls, lsz, w->lit, regen, w);
+            if (rc < 0) return rc;
+        } else {
+            if (lsz < 6) return ERR_DATA;
+            const int s1 = ls[0] | (ls[1] << 8), s2 = ls[2] | (ls[3] << 8), s3 = ls[4] | (ls[5] << 8);
+            const int s4 = lsz - 6 - s1 - s2 - s3;
+            if (s4 < 1) return ERR_DATA;
+            const int per = (regen + 3) / 4;
+            if (3 * per > regen) return ERR_DATA;
+            int rc = zstd_huf_stream(ls + 6, s1, w->lit, per, w);
+            if (rc >= 0) rc = zstd_huf_stream(ls + 6 + s1, s2, w->lit + per, per, w);
+            if (rc >= 0) rc = zstd_huf_stream(ls + 6 + s1 + s2, s3, w->lit + 2 * per, per, w);
+            if (rc >= 0) rc = zstd_huf_stream(ls + 6 + s1 + s2 + s3, s4, w->lit + 3 * per, regen - 3 * per, w);
+            if (rc < 0) return rc;
+        }
+        pos += comp;
+    }
+    // ---- sequences section
+    if (pos >= size) return ERR_DATA;
+    int nseq = src[pos++];
+    if (nseq >= 128) {
+        if (nseq == 255) { if (pos + 2 > size) return ERR_DATA; nseq = src[pos] + (src[pos + 1] << 8) + 0x7F00; pos += 2; }
+        else { if (pos + 1 > size) return ERR_DATA; nseq = ((nseq - 128) << 8) + src[pos++]; }
+    }
+    int lpos = 0;                                          // literals consumed
+    if (nseq > 0) {
+        if (pos >= size) return ERR_DATA;
+        const int modes = src[pos++];
+        if (modes & 3) return ERR_DATA;
+        for (int k = 0; k < 3; k++) {
+            const int mode = (modes >> (6 - 2 * k)) & 3;
+            ZstdFseEntry* t = k == 0 ? w->ll : k == 1 ? w->of : w->ml;
+            int* lg = k == 0 ? &w->ll_log : k == 1 ? &w->of_log : &w->ml_log;
+            const int maxsym = k == 0 ? 35 : k == 1 ? 31 : 52, maxlog = k == 0 ? 9 : k == 1 ? 8 : 9;
+            if (mode == 0) {
+                const int nsym = k == 0 ? 36 : k == 1 ? 29 : 53;
+                for (int i = 0; i < nsym; i++) w->freq[i] = (int16_t)zstd_default_freq(k, i);
+                *lg = k == 1 ? 5 : 6;
+                const int rc = zstd_fse_build(t, *lg, nsym, w);
+                if (rc < 0) return rc;
+            } else if (mode == 1) {
+                if (pos >= size) return ERR_DATA;
+                if (src[pos] > maxsym) return ERR_DATA;
+                zstd_fse_rle(t, src[pos++]);
+                *lg = 0;
+            } else if (mode == 2) {
+                int nsym = 0;
+                const int h = zstd_fse_read_header(src + pos, size - pos, maxlog, maxsym, w, lg, &nsym);
+                if (h < 0) return h;
+                const int rc = zstd_fse_build(t, *lg, nsym, w);
+                if (rc < 0) return rc;
+                pos += h;
+            } else if (!(w->have_tables & (1 << k))) return ERR_DATA;
+            w->have_tables |= 1 << k;
+        }
+        const uint8_t* bs = src + pos;
+        const int bl = size - pos;
+        if (bl < 1 || bs[bl - 1] == 0) return ERR_DATA;
+        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(bs[bl - 1]));
+        const int llm = (1 << w->ll_log) - 1, ofm = (1 << w->of_log) - 1, mlm = (1 << w->ml_log) - 1;
+        int sl = (int)zstd_rbits(bs, bl, &off, w->ll_log), so = (int)zstd_rbits(bs, bl, &off, w->of_log), sm = (int)zstd_rbits(bs, bl, &off, w->ml_log);
+        for (int i = 0; i < nseq; i++) {
+            const ZstdFseEntry el = w->ll[sl & llm], eo = w->of[so & ofm], em = w->ml[sm & mlm];
+            if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
+            const uint32_t ov = (1u << eo.sym) + zstd_rbits(bs, bl, &off, eo.sym);
+            const int mlen = zstd_ml_base(em.sym) + (int)zstd_rbits(bs, bl, &off, zstd_ml_bits(em.sym));
+            const int llen = zstd_ll_base(el.sym) + (int)zstd_rbits(bs, bl, &off, zstd_ll_bits(el.sym));
+            if (i + 1 < nseq) {
+                sl = el.base + (int)zstd_rbits(bs, bl, &off, el.nb);
+                sm = em.base + (int)zstd_rbits(bs, bl, &off, em.nb);
+                so = eo.base + (int)zstd_rbits(bs, bl, &off, eo.nb);
+            }
+            if (off < 0) return ERR_DATA;
+            int offset;
+            if (ov > 3) { offset = (int)(ov - 3); fs->rep[2] = fs->rep[1]; fs->rep[1] = fs->rep[0]; fs->rep[0] = offset; }
+            else {
+                const int idx = (int)ov + (llen == 0 ? 1 : 0);
+                if (idx == 1) offset = fs->rep[0];
+                else {
+                    offset = idx == 4 ? fs->rep[0] - 1 : fs->rep[idx - 1];
+                    if (idx > 2) fs->rep[2] = fs->rep[1];
+                    fs->rep[1] = fs->rep[0];
+                    fs->rep[0] = offset;
+                }
+            }
+            if (llen > regen - lpos || llen > dcap - dpos) return ERR_DATA;
+            for (int k = 0; k < llen; k++) dst[dpos + k] = lit[lpos + k];
+            dpos += llen; lpos += llen;
+            if (offset <= 0 || offset > dpos || mlen > dcap - dpos) return ERR_DATA;
+            for (int k = 0; k < mlen; k++) dst[dpos + k] = dst[dpos + k - offset];
+            dpos += mlen;
+        }
+        if (off != 0) return ERR_DATA;
+    }
+    const int rest = regen - lpos;
+    if (rest > dcap - dpos) return ERR_DATA;
+    for (int k = 0; k < rest; k++) dst[dpos + k] = lit[lpos + k];
+    return dpos + rest;
+}
+
+// One frame at src[0, size) -> dst[0, cap).  Returns the regenerated size or a negative blosc2 error code.
+CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int cap, ZstdWork* w)
+{
+    if (size < 6) return ERR_DATA;
+    if (!(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) return ERR_DATA;
+    const int fhd = src[4];
+    const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+    if (fhd & 0x08) return ERR_DATA;
+    if (did) return ERR_CODEC_SUPPORT;                      // dictionaries: blosc2 does not use them
+    int pos = 5 + (single ? 0 : 1);
+    const int fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : fcs_flag == 1 ? 2 : fcs_flag == 2 ? 4 : 8;
+    if (pos + fcs_bytes > size) return ERR_DATA;
+    int64_t fcs = -1;
+    if (fcs_bytes) {
+        fcs = 0;
+        for (int k = 0; k < fcs_bytes && k < 8; k++) fcs |= (int64_t)src[pos + k] << (8 * k);
+        if (fcs_bytes == 2) fcs += 256;
+        if (fcs > cap) return ERR_WRITE_BUFFER;
+    }
+    pos += fcs_bytes;
+    w->have_huf = 0; w->have_tables = 0;
+    ZstdFrameState fs;
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8;
+    int dpos = 0;
+    for (int guard = 0; guard <= size; ++guard) {
+        if (pos + 3 > size) return ERR_DATA;
+        const int bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+        pos += 3;
+        const int last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        if (type == 0) {
+            if (pos + bsz > size || bsz > cap - dpos) return ERR_DATA;
+            for (int k = 0; k < bsz; k++) dst[dpos + k] = src[pos + k];
+            dpos += bsz; pos += bsz;
+        } else if (type == 1) {
+            if (pos + 1 > size || bsz > cap - dpos) return ERR_DATA;
+            for (int k = 0; k < bsz; k++) dst[dpos + k] = src[pos];
+            dpos += bsz; pos += 1;
+        } else if (type == 2) {
+            if (pos + bsz > size) return ERR_DATA;
+            const int r = zstd_block(src + pos, bsz, dst, dpos, cap, w, &fs);
+            if (r < 0) return r;
+            dpos = r; pos += bsz;
+        } else return ERR_DATA;
+        if (last) {
+            if (checksum) pos += 4;
+            if (pos > size) return ERR_DATA;
+            if (fcs >= 0 && fcs != dpos) return ERR_DATA;
+            return dpos;
+        }
+    }
+    return ERR_DATA;
+}
+
+}  // namespace cimg

@@ -110,6 +110,14 @@ def lz4_decode(comp, n):
     return r, out[:n].tobytes()
 
 
+def zstd_decode(frame, cap):
+    """One zstd frame through csrc/zstd_decode.h: (return code = regenerated size or < 0, bytes)."""
+    c = _u8(frame)
+    out = np.zeros(max(cap, 1), np.uint8)
+    r = lib().emu_zstd_decode(_p(c), c.size, _p(out), cap)
+    return r, out[:max(r, 0)].tobytes()
+
+
 def blosclz_encode(src, cap=None, clevel=9):
     s = _u8(src)
     n = s.size

@@ -4,6 +4,7 @@
 // libcimg_hip.so; nothing in the product loads it.
 #define CIMG_EMULATE 1
 #include "plan.h"
+#include "zstd_decode.h"
 #include "deinterleave_kernel.h"
 #include "assemble_kernel.h"
 #include "blosclz_kernel.h"
@@ -166,6 +167,19 @@ int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, 
     const int r = lz4_encode_wave(lds.data(), 0, round16(n), n, dst, cap, accel, &nd);
     if (need) *need = nd;
     return r;
+}
+
+// one zstd frame through csrc/zstd_decode.h (the work area the kernel keeps in LDS is on the heap here)
+int emu_zstd_decode(const uint8_t* src, int csize, uint8_t* dst, int cap)
+{
+    std::vector<uint8_t> lit((size_t)ZSTD_LIT_CAP + 64);
+    std::vector<ZstdWork> w(1);
+    w[0].lit = lit.data();
+    std::vector<uint8_t> in(src, src + csize);            // exact-size copy: a read past the end is an ASAN finding
+    std::vector<uint8_t> out((size_t)cap);
+    const int rc = zstd_decode_frame(in.data(), csize, out.data(), cap, &w[0]);
+    if (rc > 0) memcpy(dst, out.data(), (size_t)rc);
+    return rc;
 }
 
 int emu_lz4_decode(const uint8_t* src, int csize, uint8_t* dst, int n)

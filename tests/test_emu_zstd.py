@@ -1,0 +1,52 @@
+"""The zstd frame decoder (csrc/zstd_decode.h: the read side of enums::codec::zstd, enums.h:18-24) on the host, against
+frames libzstd made (tests/golden/make_zstd_golden.py): the answer of every vector is its input."""
+import os
+
+import numpy as np
+import pytest
+
+import _emu as E
+
+
+@pytest.fixture(scope="module")
+def kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "zstd_kat.npz"))
+
+
+def test_every_golden_frame_decodes_to_its_input(kat):
+    n = 0
+    for key in kat["frames"]:
+        key = str(key)
+        src = kat["in|" + key.split("|")[0]]
+        r, out = E.zstd_decode(kat["frame|" + key], src.size + 8)
+        assert r == src.size, (key, r)
+        assert out == src.tobytes(), key
+        n += 1
+    assert n >= 100
+
+
+def test_exact_capacity_and_short_capacity(kat):
+    src = kat["in|text"]
+    fr = kat["frame|text|L3"]
+    r, out = E.zstd_decode(fr, src.size)
+    assert r == src.size and out == src.tobytes()
+    r, _ = E.zstd_decode(fr, src.size - 1)
+    assert r < 0
+
+
+def test_damaged_frames_fail_cleanly(kat):
+    """Truncations and bit flips: an error or (for a flipped literal) wrong bytes -- never a crash, never a read or write
+    outside the buffers (the emulator build of CI runs this under ASAN, tests/test_emu_fuzz.py)."""
+    rng = np.random.default_rng(5)
+    for key in ("text|L3", "natural_plane|L19", "tiled_hi_plane|L1", "skewed_16k|L5", "two_blocks_150k|L1"):
+        fr = kat["frame|" + key].copy()
+        n = kat["in|" + key.split("|")[0]].size
+        for cut in (0, 3, 5, 9, fr.size // 2, fr.size - 1):
+            r, _ = E.zstd_decode(fr[:cut], n)
+            assert r < 0, (key, cut)
+        for _ in range(60):
+            bad = fr.copy()
+            i = int(rng.integers(0, bad.size))
+            bad[i] ^= 1 << int(rng.integers(0, 8))
+            r, out = E.zstd_decode(bad, n)
+            assert r <= n
