@@ -15,6 +15,7 @@
 #include "plan.h"
 #include "assemble_kernel.h"
 #include "deinterleave_kernel.h"
+#include "zstd_kernel.h"
 #include "../../include/cimg_hip.h"
 
 using namespace cimg;
@@ -84,6 +85,15 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_lean(DecodeArgs a)
     __syncthreads();
     blk.phase_b(wave, nwaves);
     if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
+}
+
+// blocks of zstd-coded chunks, one wave per block: the slow path that keeps chunks written with enums::codec::zstd readable
+// (zstd_kernel.h); launched only behind a batch in which cimg_decode_blocks met such a chunk
+extern "C" __global__ __launch_bounds__(64) void cimg_decode_zstd(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    DecodeZstdBlock blk(a, lds, (int)blockIdx.x);
+    blk.run();
 }
 
 // the lean launch with TWO waves per block: wave 0 finds the tokens of the LZ4 chain, wave 1 moves the bytes (decode_pair.h)
@@ -191,6 +201,7 @@ struct cimg_engine {
     int lean_threads = getenv("CIMG_LEAN_THREADS") ? atoi(getenv("CIMG_LEAN_THREADS")) : 64;              // one wave per block (measured best; 64 / 128 / 256 are valid)
     uint32_t done_gen = 0;
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
+    int64_t zstd_batches = 0;           // decode batches that needed cimg_decode_zstd
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
     uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over (1: unknown yet -> general kernel enqueued up front)
     int num_cus = 256;
@@ -211,7 +222,7 @@ struct cimg_engine {
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
     bool lean_pair = getenv("CIMG_LEAN_PAIR") != nullptr && atoi(getenv("CIMG_LEAN_PAIR")) != 0;   // two waves per lean block (decode_pair.h)
-    int max_dyn_lds[5] = {0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz)
+    int max_dyn_lds[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / lean pair / zstd
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -791,7 +802,25 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
             if ((rc = cimg_engine_synchronize(e))) return rc;
         }
     }
-    const int32_t* st = (const int32_t*)e->h_dec.p;
+    int32_t* st = (int32_t*)e->h_dec.p;
+    // Chunks in a codec format the kernels above do not read came back with ERR_CODEC_SUPPORT.  zstd (format 4) has a decoder
+    // of its own -- slow, one wave per block, only ever launched here: their status is cleared, cimg_decode_zstd goes over the
+    // batch (it leaves every other chunk alone and reports formats nobody reads again), and the words are read once more.
+    bool unread = false;
+    for (int i = 0; i < nchunks; i++) if (st[i] == ERR_CODEC_SUPPORT) { st[i] = 0; unread = true; }
+    if (unread) {
+        DecodeArgs za = da;
+        za.lds_bytes = zstd_kernel_lds_bytes();
+        za.dbg = nullptr; za.done = nullptr; za.skipped = nullptr;
+        if (za.lds_bytes > e->lds_per_wg) {
+            for (int i = 0; i < nchunks; i++) if (!st[i]) st[i] = ERR_CODEC_SUPPORT;      // (cannot happen on gfx950: 160 KiB per workgroup)
+        } else {
+            if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
+            if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;
+            if ((rc = cimg_engine_synchronize(e))) return rc;
+            e->zstd_batches++;
+        }
+    }
     int first = 0;
     for (int i = 0; i < nchunks; i++) {
         if (status) status[i] = st[i];

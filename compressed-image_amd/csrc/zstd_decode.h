@@ -10,7 +10,7 @@
 // (tests/golden/zstd_kat.npz, tests/golden/make_zstd_golden.py).
 //
 // Limits (anything else is ERR_CODEC_SUPPORT / ERR_DATA, never an out-of-range access): regenerated size of a frame <= the
-// caller's capacity, literals of one block <= ZSTD_LIT_CAP, no dictionary, window = the frame itself.
+// caller's capacity, literals of one block <= the work area's lit_cap, no dictionary, window = the frame itself.
 #pragma once
 #include "codec_types.h"
 #include "wave.h"
@@ -29,7 +29,8 @@ struct ZstdWork {
     uint16_t sdesc[256];
     uint8_t weights[256];
     int32_t ll_log, ml_log, of_log, huf_log, have_huf, have_tables;
-    uint8_t* lit;            // literal buffer of ZSTD_LIT_CAP bytes
+    int32_t lit_cap;         // bytes at lit (<= ZSTD_LIT_CAP)
+    uint8_t* lit;            // literal buffer
 };
 
 // ---- bit readers --------------------------------------------------------------------------------------------------
@@ -265,7 +266,7 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
         else if (sf == 2) { hdr = 4; regen = (int)((v >> 4) & 0x3FFF); comp = (int)((v >> 18) & 0x3FFF); streams = 4; }
         else { hdr = 5; regen = (int)((v >> 4) & 0x3FFFF); comp = (int)((v >> 22) & 0x3FFFF); streams = 4; }
     }
-    if (regen > ZSTD_LIT_CAP) return ERR_CODEC_SUPPORT;
+    if (regen > w->lit_cap) return ERR_CODEC_SUPPORT;
     int pos = hdr;
     const uint8_t* lit = w->lit;
     if (ltype == 0) {

@@ -1,0 +1,93 @@
+// zstd_kernel.h -- blocks of zstd-coded chunks (blosc2 codec format 4), one wave per block.  The slow path of the decoder:
+// chunks the reference wrote with enums::codec::zstd (enums.h:18-24) stay readable; nothing here is tuned.
+//
+// The engine launches this kernel only behind a batch in which cimg_decode_blocks reported ERR_CODEC_SUPPORT for some chunk
+// (engine.hip: decompress_finish).  A block of any other chunk is left alone; a chunk with a codec format that no kernel
+// reads (zlib, user codecs) gets ERR_CODEC_SUPPORT again.  LDS: the block's streams decoded back to back, the literal buffer
+// of the frame being decoded, the entropy tables (zstd_decode.h: ZstdWork); the compressed bytes are read from HBM where they
+// lie.  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
+// un-shuffle at the end is the only lane-parallel part.
+#pragma once
+#include "decode_kernel.h"
+#include "zstd_decode.h"
+
+namespace cimg {
+
+enum : int { ZSTD_KERNEL_BLOCK_MAX = 32768 };
+CIMG_HD int zstd_kernel_lds_bytes() { return 2 * ZSTD_KERNEL_BLOCK_MAX + (int)((sizeof(ZstdWork) + 15) & ~(size_t)15) + 64; }
+
+struct DecodeZstdBlock {
+    const DecodeArgs& a;
+    uint8_t* lds;
+    int b;
+    CIMG_DEV DecodeZstdBlock(const DecodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
+
+    CIMG_DEV void run()
+    {
+        const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
+        const int j = b - d.blk0;
+        const uint8_t* c = a.comp + d.comp_off;
+        uint8_t* out = a.raw + d.raw_off + (int64_t)j * d.blocksize;
+        const int bsize = (j == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
+        const u128 h0 = ld128u(c), h1 = ld128u(c + 16);
+        const uint32_t w0 = uni(h0.x);
+        const int flags = (int)((w0 >> 16) & 0xFF), ts = (int)(w0 >> 24);
+        const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z), cbytes = (int)uni(h0.w);
+        const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
+        // whatever cimg_decode_blocks already settled -- damaged headers, special and memcpyed chunks, its own codecs -- is not ours
+        if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN) return;
+        if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) return;
+        if (((b2 >> 28) & 7) != 0 || (flags & FLAG_MEMCPYED)) return;
+        const int fmt = flags >> 5;
+        if (fmt == 0 || fmt == 1) return;
+        if (fmt != 4) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        const int filter = (int)((f1 >> 8) & 0xFF);
+        if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE)) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        if (blocksize > ZSTD_KERNEL_BLOCK_MAX || zstd_kernel_lds_bytes() > a.lds_bytes) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        const bool leftover_blk = bsize != blocksize;
+        const int ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
+        const int neblock = bsize / ns;
+        if (cbytes < HEADER_LEN + 4 * d.nblocks) { fail(chunk, ERR_READ_BUFFER); return; }
+        const int bstart = ld32s(c + HEADER_LEN + 4 * j);
+        if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { fail(chunk, ERR_DATA); return; }
+        ZstdWork* w = reinterpret_cast<ZstdWork*>(lds + 2 * ZSTD_KERNEL_BLOCK_MAX);
+        w->lit = lds + ZSTD_KERNEL_BLOCK_MAX;
+        w->lit_cap = ZSTD_KERNEL_BLOCK_MAX;
+        int pos = bstart;
+        for (int s = 0; s < ns; s++) {
+            if (cbytes - pos < 4) { fail(chunk, ERR_READ_BUFFER); return; }
+            const int cs = uni(ld32s(c + pos));
+            pos += 4;
+            const int payload = cs > 0 ? cs : (cs < 0 ? 1 : 0);
+            if (payload > cbytes - pos) { fail(chunk, ERR_READ_BUFFER); return; }
+            uint8_t* plane = lds + s * neblock;
+            if (cs <= 0) {
+                if (cs < 0 && (!(c[pos] & 1) || cs < -255)) { fail(chunk, ERR_RUN_LENGTH); return; }
+                const uint8_t v = (uint8_t)((uint32_t)(-cs) & 0xFF);
+                for (int i = 0; i < neblock; i += 64) { FOR_LANES_W(l) { if (i + l < neblock) plane[i + l] = v; } }
+            } else if (cs == neblock) {
+                for (int i = 0; i < neblock; i += 64) { FOR_LANES_W(l) { if (i + l < neblock) plane[i + l] = c[pos + i + l]; } }
+            } else if (cs > neblock) {
+                fail(chunk, ERR_DATA); return;
+            } else {
+                const int r = zstd_decode_frame(c + pos, cs, plane, neblock, w);
+                if (r != neblock) { fail(chunk, r < 0 ? r : ERR_DATA); return; }
+            }
+            pos += payload;
+        }
+        // un-shuffle (blosc's byte shuffle leaves the bsize % ts tail bytes where they were)
+        const int ne = bsize / ts;
+        const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
+        for (int i0 = 0; i0 < bsize; i0 += 64) {
+            FOR_LANES_W(l) {
+                const int i = i0 + l;
+                if (i < bsize) out[i] = (shuf && i < ne * ts) ? lds[(i % ts) * ne + i / ts] : lds[i];
+            }
+        }
+    }
+
+    CIMG_DEV void fail(int chunk, int code) { FOR_LANES_W(l) { if (l == 0) a.status[chunk] = code; } }
+};
+
+}  // namespace cimg

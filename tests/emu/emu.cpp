@@ -4,7 +4,7 @@
 // libcimg_hip.so; nothing in the product loads it.
 #define CIMG_EMULATE 1
 #include "plan.h"
-#include "zstd_decode.h"
+#include "zstd_kernel.h"
 #include "deinterleave_kernel.h"
 #include "assemble_kernel.h"
 #include "blosclz_kernel.h"
@@ -142,6 +142,20 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         for (int w = 0; w < 4; w++) ws[w]->phase_a(w);
         for (int w = 0; w < 4; w++) ws[w]->phase_b(w);
     }
+    // as the engine does (decompress_finish): chunks nobody read yet go to the zstd kernel
+    bool unread = false;
+    for (int i = 0; i < nchunks; i++) if (status[i] == ERR_CODEC_SUPPORT) { status[i] = 0; unread = true; }
+    if (unread) {
+        DecodeArgs za = da;
+        za.lds_bytes = zstd_kernel_lds_bytes();
+        za.done = nullptr;
+        std::vector<uint8_t> zl((size_t)za.lds_bytes + EMU_LDS_SLACK);
+        for (int b = 0; b < plan.total_blocks; b++) {
+            memset(zl.data(), 0xCD, zl.size());
+            DecodeZstdBlock blk(za, zl.data(), b);
+            blk.run();
+        }
+    }
     return 0;
 }
 
@@ -175,6 +189,7 @@ int emu_zstd_decode(const uint8_t* src, int csize, uint8_t* dst, int cap)
     std::vector<uint8_t> lit((size_t)ZSTD_LIT_CAP + 64);
     std::vector<ZstdWork> w(1);
     w[0].lit = lit.data();
+    w[0].lit_cap = ZSTD_LIT_CAP;
     std::vector<uint8_t> in(src, src + csize);            // exact-size copy: a read past the end is an ASAN finding
     std::vector<uint8_t> out((size_t)cap);
     const int rc = zstd_decode_frame(in.data(), csize, out.data(), cap, &w[0]);

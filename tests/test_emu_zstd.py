@@ -50,3 +50,29 @@ def test_damaged_frames_fail_cleanly(kat):
             bad[i] ^= 1 << int(rng.integers(0, 8))
             r, out = E.zstd_decode(bad, n)
             assert r <= n
+
+
+def test_blosc2_zstd_chunks_decode_through_the_kernels(kat):
+    """Chunks framed the way c-blosc2 frames enums::codec::zstd (codec format 4; split and unsplit, run tokens, stored
+    streams, leftover blocks) go lean kernel -> general kernel (ERR_CODEC_SUPPORT) -> zstd kernel, as in the engine."""
+    for name in kat["chunks"]:
+        name = str(name)
+        src = kat["cin|" + name]
+        chunk = kat["chunk|" + name]
+        bs = int(np.frombuffer(chunk[8:12].tobytes(), "<i4")[0])
+        rc, status, out = E.decompress_batch([chunk.tobytes()], [src.size], [bs])
+        assert rc == 0 and status == [0], (name, rc, status)
+        assert out[0].tobytes() == src.tobytes(), name
+
+
+def test_a_damaged_zstd_chunk_reports_an_error_and_leaves_its_neighbours_alone(kat):
+    good = kat["chunk|tiled_u16_split"]
+    src = kat["cin|tiled_u16_split"]
+    bad = good.copy()
+    at = good.tobytes().find(b"\x28\xb5\x2f\xfd")            # the first stream that is a zstd frame
+    assert at > 32
+    bad[at + 5:at + 40] ^= 0x5A
+    bs = int(np.frombuffer(good[8:12].tobytes(), "<i4")[0])
+    rc, status, out = E.decompress_batch([good.tobytes(), bad.tobytes(), good.tobytes()], [src.size] * 3, [bs] * 3)
+    assert status[0] == 0 and status[2] == 0 and status[1] < 0
+    assert out[0].tobytes() == src.tobytes() and out[2].tobytes() == src.tobytes()

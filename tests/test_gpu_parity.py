@@ -725,3 +725,31 @@ def test_lz4hc_chunks_decode_on_the_gpu(eng, golden_dir):
     assert not status.any()
     for n, o in zip(kat["cases"], outs):
         assert o.tobytes() == kat["in|" + str(n)].tobytes(), n
+
+
+def test_zstd_chunks_decode_on_the_gpu(eng, golden_dir):
+    """enums::codec::zstd chunks (streams = frames of the system libzstd, tests/golden/make_zstd_golden.py) are codec format 4:
+    cimg_decode_blocks hands them to cimg_decode_zstd (csrc/zstd_kernel.h, the slow path).  Alone, and mixed into a batch with
+    LZ4 chunks; a damaged one fails by itself.  Compressing with zstd stays refused (test_empty_batch_and_unsupported...)."""
+    kat = np.load(os.path.join(golden_dir, "zstd_kat.npz"))
+    names = [str(n) for n in kat["chunks"]]
+    chunks = [kat["chunk|" + n].tobytes() for n in names]
+    outs, status = eng.decompress_host(chunks)
+    assert not status.any()
+    for n, o in zip(names, outs):
+        assert o.tobytes() == kat["cin|" + n].tobytes(), n
+    # mixed with chunks of this engine's own codecs
+    a = synth.tiled_channel(np.float16, 512, 64)
+    (lz,) = eng.compress_host(hip.cparams(2), a, [a.nbytes], [a.nbytes + 32])
+    outs, status = eng.decompress_host([lz, chunks[0], lz, chunks[2]])
+    assert not status.any()
+    assert outs[0].tobytes() == a.tobytes() and outs[2].tobytes() == a.tobytes()
+    assert outs[1].tobytes() == kat["cin|" + names[0]].tobytes() and outs[3].tobytes() == kat["cin|" + names[2]].tobytes()
+    # damage inside the first zstd frame of a chunk: that chunk fails, its neighbour is decoded
+    bad = bytearray(chunks[0])
+    at = chunks[0].find(b"\x28\xb5\x2f\xfd")
+    for k in range(at + 5, at + 40):
+        bad[k] ^= 0x5A
+    outs, status = eng.decompress_host([chunks[1], bytes(bad)], check=False)
+    assert status[0] == 0 and status[1] < 0
+    assert outs[0].tobytes() == kat["cin|" + names[1]].tobytes()
