@@ -119,7 +119,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			p.nthreads = static_cast<int16_t>(nthreads == 0 ? 1 : nthreads);    // accepted, ignored: the parallelism is the GPU's
 			p.compcode = codec_to_blosc2(codec);
 			// fail where the choice is made, not at the first chunk: the MI355X path encodes lz4 and blosclz
-			// (lz4hc chunks written elsewhere still decode; zstd is not on the path at all)
+			// (lz4hc and zstd chunks written elsewhere still decode)
 			if (codec == enums::codec::lz4hc || codec == enums::codec::zstd)
 				throw std::runtime_error(detail::text("codec ", codec == enums::codec::zstd ? "zstd" : "lz4hc",
 					" is not available for compression on the MI355X GPU path (available: lz4, blosclz)"));

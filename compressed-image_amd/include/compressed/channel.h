@@ -62,6 +62,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			if (have != width * height)
 				throw std::invalid_argument(detail::text("Invalid schunk passed to compressed::channel constructor. Expected a size of ", width * height, " but instead got ", have));
 			m_Schunk = std::make_shared<blosc2::schunk_var<T>>(std::move(schunk));
+			m_Adopted = true;
 			make_contexts(block_size());
 		}
 
@@ -82,8 +83,8 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		}
 		static channel zeros_like(const channel& other) { return full_like(other, T{}); }
 
-		iterator begin() { return iterator(m_Schunk, m_CompressionContext.get(), m_DecompressionContext.get(), 0, m_Width, m_Height); }
-		iterator end() { return iterator(m_Schunk, m_CompressionContext.get(), m_DecompressionContext.get(), num_chunks(), m_Width, m_Height); }
+		iterator begin() { require_encoder(); return iterator(m_Schunk, m_CompressionContext.get(), m_DecompressionContext.get(), 0, m_Width, m_Height); }
+		iterator end() { require_encoder(); return iterator(m_Schunk, m_CompressionContext.get(), m_DecompressionContext.get(), num_chunks(), m_Width, m_Height); }
 
 		blosc2::context_raw_ptr compression_context() { return m_CompressionContext.get(); }
 		blosc2::context_raw_ptr decompression_context() { return m_DecompressionContext.get(); }
@@ -117,6 +118,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		void set_chunk(std::span<T> buffer, size_t chunk_idx)
 		{
 			require();
+			require_encoder();
 			std::visit([&](auto& s) { s.set_chunk(m_CompressionContext, buffer, chunk_idx); }, *m_Schunk);
 		}
 		/// Decode into caller-owned memory (uncompressed_size() elements): no intermediate vector, no zero fill.
@@ -148,13 +150,23 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		blosc2::context_ptr m_CompressionContext = nullptr;
 		blosc2::context_ptr m_DecompressionContext = nullptr;
 		uint8_t m_CompressionLevel = 9;
+		bool m_Adopted = false;
 		size_t m_Width = 1;
 		size_t m_Height = 1;
 
+		// `adopted`: the chunks exist already.  A table written elsewhere with a codec this path only READS (lz4hc, zstd) is
+		// adopted without a compression context: its chunks decode, anything that would re-encode one (set_chunk, the
+		// iterator) throws.  Everywhere else a decode-only codec fails here, where the choice is made.
 		void make_contexts(size_t block_size)
 		{
-			m_CompressionContext = blosc2::create_compression_context<T>(m_Nthreads, m_Codec, m_CompressionLevel, block_size);
+			const bool read_only = m_Adopted && (m_Codec == enums::codec::lz4hc || m_Codec == enums::codec::zstd);
+			m_CompressionContext = read_only ? blosc2::context_ptr(nullptr) : blosc2::create_compression_context<T>(m_Nthreads, m_Codec, m_CompressionLevel, block_size);
 			m_DecompressionContext = blosc2::create_decompression_context(m_Nthreads);
+		}
+		void require_encoder() const
+		{
+			if (!m_CompressionContext)
+				throw std::runtime_error("this channel's codec (lz4hc / zstd) is decode-only on the MI355X GPU path: its chunks can be read, not rewritten");
 		}
 		void require() const
 		{

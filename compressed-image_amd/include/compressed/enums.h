@@ -11,7 +11,7 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			blosclz,   // GPU encode + decode (bytes of BloscLZ 2.3.0, csrc/blosclz_kernel.h)
 			lz4,       // GPU encode + decode (the reference's default, channel.h:101)
 			lz4hc,     // decode only (codec format 1 = LZ4 blocks); compressing fails with BLOSC2_ERROR_CODEC_SUPPORT
-			zstd       // not on the GPU path: fails with BLOSC2_ERROR_CODEC_SUPPORT
+			zstd       // decode only (codec format 4, csrc/zstd_kernel.h: a slow path); compressing fails with BLOSC2_ERROR_CODEC_SUPPORT
 		};
 	}
 }
