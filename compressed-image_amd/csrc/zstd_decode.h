@@ -14,6 +14,7 @@
 #pragma once
 #include "codec_types.h"
 #include "wave.h"
+#include <cstring>
 
 namespace cimg {
 
@@ -29,6 +30,7 @@ struct ZstdWork {
     uint16_t sdesc[256];
     uint8_t weights[256];
     int32_t ll_log, ml_log, of_log, huf_log, have_huf, have_tables;
+    int32_t rank_count[ZSTD_HUF_LOG_MAX + 2], rank_idx[ZSTD_HUF_LOG_MAX + 2];
     int32_t lit_cap;         // bytes at lit (<= ZSTD_LIT_CAP)
     uint8_t* lit;            // literal buffer
 };
@@ -40,6 +42,10 @@ CIMG_HD uint32_t zstd_bits(const uint8_t* src, int size, int64_t off, int n)
     if (n <= 0) return 0;
     uint64_t acc = 0;
     const int64_t b0 = off >> 3;
+    if (b0 >= 0 && b0 + 8 <= size) {                   // the usual case: eight bytes in one (unaligned) load
+        memcpy(&acc, src + b0, 8);
+        return (uint32_t)((acc >> (off & 7)) & ((1ull << n) - 1));
+    }
     for (int k = 0; k < 5; k++) {
         const int64_t b = b0 + k;
         const uint64_t v = (b >= 0 && b < size) ? src[b] : 0;
@@ -212,7 +218,8 @@ CIMG_HD int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
     if (left & (left - 1)) return ERR_DATA;
     w->weights[n++] = (uint8_t)(zstd_highbit(left) + 1);
     // code lengths -> table: longest codes first, symbols in ascending order within a length
-    int rank_count[ZSTD_HUF_LOG_MAX + 2], rank_idx[ZSTD_HUF_LOG_MAX + 2];
+    int32_t* rank_count = w->rank_count;               // (in the work area, not on the stack: a private array is scratch memory on the device)
+    int32_t* rank_idx = w->rank_idx;
     for (int i = 0; i <= ZSTD_HUF_LOG_MAX + 1; i++) rank_count[i] = 0;
     for (int i = 0; i < n; i++) { const int b = w->weights[i] ? maxbits + 1 - w->weights[i] : 0; w->weights[i] = (uint8_t)b; rank_count[b]++; }
     rank_idx[maxbits] = 0;
@@ -246,8 +253,30 @@ CIMG_HD int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int coun
     return (off == -log && n == count) ? 0 : ERR_DATA;
 }
 
+// ---- byte movers: the only lane-parallel part of the decoder (64 bytes per step) -------------------------------------------
+// non-overlapping copy
+CIMG_HD void zstd_copy(uint8_t* dst, const uint8_t* src, int n)
+{
+    for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = src[k0 + l]; } }
+}
+CIMG_HD void zstd_fill(uint8_t* dst, uint8_t v, int n)
+{
+    for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = v; } }
+}
+// dst[k] = dst[k - offset], k = 0 .. n-1 in order: with offset < 64 the source is the repeating pattern in front of dst
+CIMG_HD void zstd_match(uint8_t* dst, int offset, int n)
+{
+    if (offset >= 64) {
+        // (a step reads [k0 - offset, k0 + 64 - offset), all of it in front of the 64 bytes it writes)
+        for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = dst[k0 + l - offset]; } }
+        return;
+    }
+    const uint8_t* pat = dst - offset;
+    for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = pat[(k0 + l) % offset]; } }
+}
+
 // ---- one compressed block ---------------------------------------------------------------------------------------------
-struct ZstdFrameState { int rep[3]; };
+struct ZstdFrameState { int r0, r1, r2; };      // the three repeat offsets
 
 CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int dcap, ZstdWork* w, ZstdFrameState* fs)
 {
@@ -275,7 +304,7 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
         pos += regen;
     } else if (ltype == 1) {
         if (pos + 1 > size) return ERR_DATA;
-        for (int i = 0; i < regen; i++) w->lit[i] = src[pos];
+        zstd_fill(w->lit, src[pos], regen);
         pos += 1;
     } else {
         if (pos + comp > size) return ERR_DATA;
@@ -348,6 +377,7 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
         int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(bs[bl - 1]));
         const int llm = (1 << w->ll_log) - 1, ofm = (1 << w->of_log) - 1, mlm = (1 << w->ml_log) - 1;
         int sl = (int)zstd_rbits(bs, bl, &off, w->ll_log), so = (int)zstd_rbits(bs, bl, &off, w->of_log), sm = (int)zstd_rbits(bs, bl, &off, w->ml_log);
+        int r0 = fs->r0, r1 = fs->r1, r2 = fs->r2;
         for (int i = 0; i < nseq; i++) {
             const ZstdFseEntry el = w->ll[sl & llm], eo = w->of[so & ofm], em = w->ml[sm & mlm];
             if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
@@ -360,30 +390,28 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
                 so = eo.base + (int)zstd_rbits(bs, bl, &off, eo.nb);
             }
             if (off < 0) return ERR_DATA;
+            // (three named scalars, no indexing by idx: a dynamically indexed private array is scratch memory on the device)
             int offset;
-            if (ov > 3) { offset = (int)(ov - 3); fs->rep[2] = fs->rep[1]; fs->rep[1] = fs->rep[0]; fs->rep[0] = offset; }
+            if (ov > 3) { offset = (int)(ov - 3); r2 = r1; r1 = r0; r0 = offset; }
             else {
                 const int idx = (int)ov + (llen == 0 ? 1 : 0);
-                if (idx == 1) offset = fs->rep[0];
-                else {
-                    offset = idx == 4 ? fs->rep[0] - 1 : fs->rep[idx - 1];
-                    if (idx > 2) fs->rep[2] = fs->rep[1];
-                    fs->rep[1] = fs->rep[0];
-                    fs->rep[0] = offset;
-                }
+                if (idx == 1) offset = r0;
+                else if (idx == 2) { offset = r1; r1 = r0; r0 = offset; }
+                else { offset = idx == 3 ? r2 : r0 - 1; r2 = r1; r1 = r0; r0 = offset; }
             }
             if (llen > regen - lpos || llen > dcap - dpos) return ERR_DATA;
-            for (int k = 0; k < llen; k++) dst[dpos + k] = lit[lpos + k];
+            zstd_copy(dst + dpos, lit + lpos, llen);
             dpos += llen; lpos += llen;
             if (offset <= 0 || offset > dpos || mlen > dcap - dpos) return ERR_DATA;
-            for (int k = 0; k < mlen; k++) dst[dpos + k] = dst[dpos + k - offset];
+            zstd_match(dst + dpos, offset, mlen);
             dpos += mlen;
         }
         if (off != 0) return ERR_DATA;
+        fs->r0 = r0; fs->r1 = r1; fs->r2 = r2;
     }
     const int rest = regen - lpos;
     if (rest > dcap - dpos) return ERR_DATA;
-    for (int k = 0; k < rest; k++) dst[dpos + k] = lit[lpos + k];
+    zstd_copy(dst + dpos, lit + lpos, rest);
     return dpos + rest;
 }
 
@@ -409,7 +437,7 @@ CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int ca
     pos += fcs_bytes;
     w->have_huf = 0; w->have_tables = 0;
     ZstdFrameState fs;
-    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8;
+    fs.r0 = 1; fs.r1 = 4; fs.r2 = 8;
     int dpos = 0;
     for (int guard = 0; guard <= size; ++guard) {
         if (pos + 3 > size) return ERR_DATA;
@@ -418,11 +446,11 @@ CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int ca
         const int last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
         if (type == 0) {
             if (pos + bsz > size || bsz > cap - dpos) return ERR_DATA;
-            for (int k = 0; k < bsz; k++) dst[dpos + k] = src[pos + k];
+            zstd_copy(dst + dpos, src + pos, bsz);
             dpos += bsz; pos += bsz;
         } else if (type == 1) {
             if (pos + 1 > size || bsz > cap - dpos) return ERR_DATA;
-            for (int k = 0; k < bsz; k++) dst[dpos + k] = src[pos];
+            zstd_fill(dst + dpos, src[pos], bsz);
             dpos += bsz; pos += 1;
         } else if (type == 2) {
             if (pos + bsz > size) return ERR_DATA;

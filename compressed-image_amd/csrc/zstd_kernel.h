@@ -4,8 +4,8 @@
 // The engine launches this kernel only behind a batch in which cimg_decode_blocks reported ERR_CODEC_SUPPORT for some chunk
 // (engine.hip: decompress_finish).  A block of any other chunk is left alone; a chunk with a codec format that no kernel
 // reads (zlib, user codecs) gets ERR_CODEC_SUPPORT again.  LDS: the block's streams decoded back to back, the literal buffer
-// of the frame being decoded, the entropy tables (zstd_decode.h: ZstdWork); the compressed bytes are read from HBM where they
-// lie.  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
+// of the frame being decoded, the entropy tables (zstd_decode.h: ZstdWork) and a copy of the frame itself (108 KiB: one block
+// per CU).  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
 // un-shuffle at the end is the only lane-parallel part.
 #pragma once
 #include "decode_kernel.h"
@@ -14,7 +14,9 @@
 namespace cimg {
 
 enum : int { ZSTD_KERNEL_BLOCK_MAX = 32768 };
-CIMG_HD int zstd_kernel_lds_bytes() { return 2 * ZSTD_KERNEL_BLOCK_MAX + (int)((sizeof(ZstdWork) + 15) & ~(size_t)15) + 64; }
+CIMG_HD int zstd_work_bytes() { return (int)((sizeof(ZstdWork) + 15) & ~(size_t)15); }
+// the block's planes | the literal buffer | the entropy tables | the frame being decoded (copied in: the decoder reads it bit by bit)
+CIMG_HD int zstd_kernel_lds_bytes() { return 2 * ZSTD_KERNEL_BLOCK_MAX + zstd_work_bytes() + 64; }
 
 struct DecodeZstdBlock {
     const DecodeArgs& a;
