@@ -753,3 +753,15 @@ def test_zstd_chunks_decode_on_the_gpu(eng, golden_dir):
     outs, status = eng.decompress_host([chunks[1], bytes(bad)], check=False)
     assert status[0] == 0 and status[1] < 0
     assert outs[0].tobytes() == kat["cin|" + names[1]].tobytes()
+    # ... and through the reference's own entry point, one chunk per call (blosc2/wrapper.h:236-259 -> blosc2_decompress_ctx)
+    L = hip.load()
+    dp = hip.Blosc2DParams()
+    dp.nthreads = 1
+    dctx = L.blosc2_create_dctx(dp)
+    for n, c in zip(names, chunks):
+        want = kat["cin|" + n]
+        buf = np.frombuffer(c, np.uint8).copy()
+        out = np.zeros(want.size, np.uint8)
+        assert L.blosc2_decompress_ctx(dctx, buf.ctypes.data, buf.size, out.ctypes.data, out.size) == want.size, n
+        assert out.tobytes() == want.tobytes(), n
+    L.blosc2_free_ctx(dctx)
