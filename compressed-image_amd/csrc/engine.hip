@@ -806,14 +806,14 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     // Chunks in a codec format the kernels above do not read came back with ERR_CODEC_SUPPORT.  zstd (format 4) has a decoder
     // of its own -- slow, one wave per block, only ever launched here: their status is cleared, cimg_decode_zstd goes over the
     // batch (it leaves every other chunk alone and reports formats nobody reads again), and the words are read once more.
-    bool unread = false;
-    for (int i = 0; i < nchunks; i++) if (st[i] == ERR_CODEC_SUPPORT) { st[i] = 0; unread = true; }
-    if (unread) {
+    std::vector<int> unread_chunks;
+    for (int i = 0; i < nchunks; i++) if (st[i] == ERR_CODEC_SUPPORT) { st[i] = 0; unread_chunks.push_back(i); }
+    if (!unread_chunks.empty()) {
         DecodeArgs za = da;
         za.lds_bytes = zstd_kernel_lds_bytes();
         za.dbg = nullptr; za.done = nullptr; za.skipped = nullptr;
         if (za.lds_bytes > e->lds_per_wg) {
-            for (int i = 0; i < nchunks; i++) if (!st[i]) st[i] = ERR_CODEC_SUPPORT;      // (cannot happen on gfx950: 160 KiB per workgroup)
+            for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // (cannot happen on gfx950: 160 KiB per workgroup)
         } else {
             if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
             if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;

@@ -37,24 +37,24 @@ struct ZstdWork {
 
 // ---- bit readers --------------------------------------------------------------------------------------------------
 // bits [off, off + n) of src (LSB-first within bytes), n <= 32; bytes outside [0, size) read as zero
-CIMG_HD uint32_t zstd_bits(const uint8_t* src, int size, int64_t off, int n)
+CIMG_DEV uint32_t zstd_bits(const uint8_t* src, int size, int64_t off, int n)
 {
     if (n <= 0) return 0;
     uint64_t acc = 0;
     const int64_t b0 = off >> 3;
     if (b0 >= 0 && b0 + 8 <= size) {                   // the usual case: eight bytes in one (unaligned) load
         memcpy(&acc, src + b0, 8);
-        return (uint32_t)((acc >> (off & 7)) & ((1ull << n) - 1));
+        return uni((uint32_t)((acc >> (off & 7)) & ((1ull << n) - 1)));
     }
     for (int k = 0; k < 5; k++) {
         const int64_t b = b0 + k;
         const uint64_t v = (b >= 0 && b < size) ? src[b] : 0;
         acc |= v << (8 * k);
     }
-    return (uint32_t)((acc >> (off & 7)) & ((1ull << n) - 1));
+    return uni((uint32_t)((acc >> (off & 7)) & ((1ull << n) - 1)));
 }
 // backward stream: *off is the bit position just above the next bits; bits below position 0 read as zero
-CIMG_HD uint32_t zstd_rbits(const uint8_t* src, int size, int64_t* off, int n)
+CIMG_DEV uint32_t zstd_rbits(const uint8_t* src, int size, int64_t* off, int n)
 {
     *off -= n;
     if (n <= 0) return 0;
@@ -63,11 +63,13 @@ CIMG_HD uint32_t zstd_rbits(const uint8_t* src, int size, int64_t* off, int n)
     if (miss >= n) return 0;
     return zstd_bits(src, size, 0, (int)(n - miss)) << miss;
 }
-CIMG_HD int zstd_highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
+// a byte every lane reads from the same address: wave-uniform, and said so (the decoder's control flow then stays scalar)
+CIMG_DEV int zstd_u8(const uint8_t* p, int i) { return (int)uni((uint32_t)p[i]); }
+CIMG_DEV int zstd_highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
 // ---- FSE ------------------------------------------------------------------------------------------------------------
 // table description at src[0..size): fills w->freq, returns bytes consumed (< 0: error); *log_out = accuracy log
-CIMG_HD int zstd_fse_read_header(const uint8_t* src, int size, int max_log, int max_sym, ZstdWork* w, int* log_out, int* nsym_out)
+CIMG_DEV int zstd_fse_read_header(const uint8_t* src, int size, int max_log, int max_sym, ZstdWork* w, int* log_out, int* nsym_out)
 {
     int64_t off = 0;
     const int log = 5 + (int)zstd_bits(src, size, off, 4);
@@ -104,26 +106,28 @@ CIMG_HD int zstd_fse_read_header(const uint8_t* src, int size, int max_log, int 
     return used > size ? ERR_DATA : used;
 }
 
-CIMG_HD int zstd_fse_build(ZstdFseEntry* t, int log, int nsym, ZstdWork* w)
+CIMG_DEV int zstd_fse_build(ZstdFseEntry* t, int log, int nsym, ZstdWork* w)
 {
     const int size = 1 << log;
     int high = size;
     for (int s = 0; s < nsym; s++)
-        if (w->freq[s] == -1) { t[--high].sym = (uint8_t)s; w->sdesc[s] = 1; }
+        if (uni((int)w->freq[s]) == -1) { t[--high].sym = (uint8_t)s; w->sdesc[s] = 1; }
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     int pos = 0;
     for (int s = 0; s < nsym; s++) {
-        if (w->freq[s] <= 0) continue;
-        w->sdesc[s] = (uint16_t)w->freq[s];
-        for (int i = 0; i < w->freq[s]; i++) {
+        const int fr = uni((int)w->freq[s]);
+        if (fr <= 0) continue;
+        w->sdesc[s] = (uint16_t)fr;
+        for (int i = 0; i < fr; i++) {
             t[pos].sym = (uint8_t)s;
             do { pos = (pos + step) & mask; } while (pos >= high);
         }
     }
     if (pos != 0) return ERR_DATA;
     for (int i = 0; i < size; i++) {
-        const int s = t[i].sym;
-        const int next = w->sdesc[s]++;
+        const int s = uni((int)t[i].sym);
+        const int next = uni((int)w->sdesc[s]);
+        w->sdesc[s] = (uint16_t)(next + 1);
         const int nb = log - zstd_highbit((uint32_t)next);
         t[i].nb = (uint8_t)nb;
         t[i].base = (uint16_t)((next << nb) - size);
@@ -131,10 +135,10 @@ CIMG_HD int zstd_fse_build(ZstdFseEntry* t, int log, int nsym, ZstdWork* w)
     return 0;
 }
 
-CIMG_HD void zstd_fse_rle(ZstdFseEntry* t, int sym) { t[0].sym = (uint8_t)sym; t[0].nb = 0; t[0].base = 0; }
+CIMG_DEV void zstd_fse_rle(ZstdFseEntry* t, int sym) { t[0].sym = (uint8_t)sym; t[0].nb = 0; t[0].base = 0; }
 
 // predefined distributions (RFC 8878 section 3.1.1.3.2.2)
-CIMG_HD int zstd_default_freq(int which, int i)
+CIMG_DEV int zstd_default_freq(int which, int i)
 {
     // which: 0 literal lengths (36 symbols, log 6), 1 offsets (29, log 5), 2 match lengths (53, log 6)
     if (which == 0) {
@@ -157,9 +161,9 @@ CIMG_HD int zstd_default_freq(int which, int i)
     return 1;
 }
 
-CIMG_HD int zstd_ll_base(int c) { return c < 16 ? c : c < 20 ? 16 + 2 * (c - 16) : c < 22 ? 24 + 4 * (c - 20) : c < 24 ? 32 + 8 * (c - 22) : c == 24 ? 48 : 64 << (c - 25); }
-CIMG_HD int zstd_ll_bits(int c) { return c < 16 ? 0 : c < 20 ? 1 : c < 22 ? 2 : c < 24 ? 3 : c == 24 ? 4 : c - 19; }
-CIMG_HD int zstd_ml_base(int c)
+CIMG_DEV int zstd_ll_base(int c) { return c < 16 ? c : c < 20 ? 16 + 2 * (c - 16) : c < 22 ? 24 + 4 * (c - 20) : c < 24 ? 32 + 8 * (c - 22) : c == 24 ? 48 : 64 << (c - 25); }
+CIMG_DEV int zstd_ll_bits(int c) { return c < 16 ? 0 : c < 20 ? 1 : c < 22 ? 2 : c < 24 ? 3 : c == 24 ? 4 : c - 19; }
+CIMG_DEV int zstd_ml_base(int c)
 {
     if (c < 32) return c + 3;
     if (c < 36) return 35 + 2 * (c - 32);
@@ -169,20 +173,20 @@ CIMG_HD int zstd_ml_base(int c)
     if (c == 42) return 99;
     return (128 << (c - 43)) + 3;
 }
-CIMG_HD int zstd_ml_bits(int c) { return c < 32 ? 0 : c < 36 ? 1 : c < 38 ? 2 : c < 40 ? 3 : c < 42 ? 4 : c == 42 ? 5 : c - 36; }
+CIMG_DEV int zstd_ml_bits(int c) { return c < 32 ? 0 : c < 36 ? 1 : c < 38 ? 2 : c < 40 ? 3 : c < 42 ? 4 : c == 42 ? 5 : c - 36; }
 
 // ---- Huffman ----------------------------------------------------------------------------------------------------------
 // tree description at src: fills the decoding table, returns bytes consumed
-CIMG_HD int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
+CIMG_DEV int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
 {
     if (size < 1) return ERR_DATA;
-    const int hb = src[0];
+    const int hb = zstd_u8(src, 0);
     int n = 0, used;
     if (hb >= 128) {
         n = hb - 127;
         used = 1 + (n + 1) / 2;
         if (used > size) return ERR_DATA;
-        for (int i = 0; i < n; i++) w->weights[i] = (i & 1) ? (src[1 + i / 2] & 15) : (src[1 + i / 2] >> 4);
+        for (int i = 0; i < n; i++) w->weights[i] = (i & 1) ? (zstd_u8(src, 1 + i / 2) & 15) : (zstd_u8(src, 1 + i / 2) >> 4);
     } else {
         if (hb == 0 || 1 + hb > size) return ERR_DATA;
         const uint8_t* f = src + 1;
@@ -193,24 +197,24 @@ CIMG_HD int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
         if (rc < 0) return rc;
         const uint8_t* bs = f + h;
         const int bl = hb - h;
-        if (bl < 1 || bs[bl - 1] == 0) return ERR_DATA;
-        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(bs[bl - 1]));
+        if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
+        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1)));
         const int mask = (1 << log) - 1;
         int s1 = (int)zstd_rbits(bs, bl, &off, log), s2 = (int)zstd_rbits(bs, bl, &off, log);
         for (;;) {
             if (n >= 254) return ERR_DATA;
             w->weights[n++] = w->wt[s1 & mask].sym;
-            s1 = w->wt[s1 & mask].base + (int)zstd_rbits(bs, bl, &off, w->wt[s1 & mask].nb);
+            s1 = uni((int)w->wt[s1 & mask].base) + (int)zstd_rbits(bs, bl, &off, uni((int)w->wt[s1 & mask].nb));
             if (off < 0) { w->weights[n++] = w->wt[s2 & mask].sym; break; }
             w->weights[n++] = w->wt[s2 & mask].sym;
-            s2 = w->wt[s2 & mask].base + (int)zstd_rbits(bs, bl, &off, w->wt[s2 & mask].nb);
+            s2 = uni((int)w->wt[s2 & mask].base) + (int)zstd_rbits(bs, bl, &off, uni((int)w->wt[s2 & mask].nb));
             if (off < 0) { w->weights[n++] = w->wt[s1 & mask].sym; break; }
         }
         used = 1 + hb;
     }
     // the last weight is implied: the sum of 2^(w-1) is a power of two
     uint32_t sum = 0;
-    for (int i = 0; i < n; i++) { if (w->weights[i] > ZSTD_HUF_LOG_MAX) return ERR_DATA; if (w->weights[i]) sum += 1u << (w->weights[i] - 1); }
+    for (int i = 0; i < n; i++) { const int wt = uni((int)w->weights[i]); if (wt > ZSTD_HUF_LOG_MAX) return ERR_DATA; if (wt) sum += 1u << (wt - 1); }
     if (sum == 0) return ERR_DATA;
     const int maxbits = zstd_highbit(sum) + 1;
     if (maxbits > ZSTD_HUF_LOG_MAX) return ERR_DATA;
@@ -221,33 +225,34 @@ CIMG_HD int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
     int32_t* rank_count = w->rank_count;               // (in the work area, not on the stack: a private array is scratch memory on the device)
     int32_t* rank_idx = w->rank_idx;
     for (int i = 0; i <= ZSTD_HUF_LOG_MAX + 1; i++) rank_count[i] = 0;
-    for (int i = 0; i < n; i++) { const int b = w->weights[i] ? maxbits + 1 - w->weights[i] : 0; w->weights[i] = (uint8_t)b; rank_count[b]++; }
+    for (int i = 0; i < n; i++) { const int wt = uni((int)w->weights[i]); const int b = wt ? maxbits + 1 - wt : 0; w->weights[i] = (uint8_t)b; rank_count[b] = uni((int)rank_count[b]) + 1; }
     rank_idx[maxbits] = 0;
-    for (int i = maxbits; i >= 1; i--) rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1 << (maxbits - i));
-    if (rank_idx[0] != (1 << maxbits)) return ERR_DATA;
+    for (int i = maxbits; i >= 1; i--) rank_idx[i - 1] = uni((int)rank_idx[i]) + uni((int)rank_count[i]) * (1 << (maxbits - i));
+    if (uni((int)rank_idx[0]) != (1 << maxbits)) return ERR_DATA;
     for (int i = 0; i < n; i++) {
-        const int b = w->weights[i];
+        const int b = uni((int)w->weights[i]);
         if (!b) continue;
-        const int len = 1 << (maxbits - b);
-        for (int k = 0; k < len; k++) { w->huf_sym[rank_idx[b] + k] = (uint8_t)i; w->huf_nb[rank_idx[b] + k] = (uint8_t)b; }
-        rank_idx[b] += len;
+        const int len = 1 << (maxbits - b), at = uni((int)rank_idx[b]);
+        // (the 2^(maxbits - b) entries of a code: 64 per step)
+        for (int k0 = 0; k0 < len; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < len) { w->huf_sym[at + k0 + l] = (uint8_t)i; w->huf_nb[at + k0 + l] = (uint8_t)b; } } }
+        rank_idx[b] = at + len;
     }
     w->huf_log = maxbits;
     w->have_huf = 1;
     return used;
 }
 
-CIMG_HD int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int count, const ZstdWork* w)
+CIMG_DEV int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int count, const ZstdWork* w)
 {
-    if (size < 1 || src[size - 1] == 0) return ERR_DATA;
+    if (size < 1 || zstd_u8(src, size - 1) == 0) return ERR_DATA;
     const int log = w->huf_log, mask = (1 << log) - 1;
-    int64_t off = (int64_t)size * 8 - (8 - zstd_highbit(src[size - 1]));
+    int64_t off = (int64_t)size * 8 - (8 - zstd_highbit(zstd_u8(src, size - 1)));
     int state = (int)zstd_rbits(src, size, &off, log);
     int n = 0;
     while (off > -log) {
         if (n >= count) return ERR_DATA;
         out[n++] = w->huf_sym[state & mask];
-        const int nb = w->huf_nb[state & mask];
+        const int nb = (int)uni((uint32_t)w->huf_nb[state & mask]);
         state = ((state << nb) + (int)zstd_rbits(src, size, &off, nb)) & mask;
     }
     return (off == -log && n == count) ? 0 : ERR_DATA;
@@ -255,16 +260,16 @@ CIMG_HD int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int coun
 
 // ---- byte movers: the only lane-parallel part of the decoder (64 bytes per step) -------------------------------------------
 // non-overlapping copy
-CIMG_HD void zstd_copy(uint8_t* dst, const uint8_t* src, int n)
+CIMG_DEV void zstd_copy(uint8_t* dst, const uint8_t* src, int n)
 {
     for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = src[k0 + l]; } }
 }
-CIMG_HD void zstd_fill(uint8_t* dst, uint8_t v, int n)
+CIMG_DEV void zstd_fill(uint8_t* dst, uint8_t v, int n)
 {
     for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = v; } }
 }
 // dst[k] = dst[k - offset], k = 0 .. n-1 in order: with offset < 64 the source is the repeating pattern in front of dst
-CIMG_HD void zstd_match(uint8_t* dst, int offset, int n)
+CIMG_DEV void zstd_match(uint8_t* dst, int offset, int n)
 {
     if (offset >= 64) {
         // (a step reads [k0 - offset, k0 + 64 - offset), all of it in front of the 64 bytes it writes)
@@ -278,19 +283,19 @@ CIMG_HD void zstd_match(uint8_t* dst, int offset, int n)
 // ---- one compressed block ---------------------------------------------------------------------------------------------
 struct ZstdFrameState { int r0, r1, r2; };      // the three repeat offsets
 
-CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int dcap, ZstdWork* w, ZstdFrameState* fs)
+CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int dcap, ZstdWork* w, ZstdFrameState* fs)
 {
     if (size < 1) return ERR_DATA;
     // ---- literals section
-    const int ltype = src[0] & 3, sf = (src[0] >> 2) & 3;
+    const int ltype = zstd_u8(src, 0) & 3, sf = (zstd_u8(src, 0) >> 2) & 3;
     int regen, comp = 0, hdr, streams = 1;
     if (ltype < 2) {
-        if (sf == 0 || sf == 2) { hdr = 1; regen = src[0] >> 3; }
-        else if (sf == 1) { hdr = 2; if (size < 2) return ERR_DATA; regen = (src[0] >> 4) | (src[1] << 4); }
-        else { hdr = 3; if (size < 3) return ERR_DATA; regen = (src[0] >> 4) | (src[1] << 4) | (src[2] << 12); }
+        if (sf == 0 || sf == 2) { hdr = 1; regen = zstd_u8(src, 0) >> 3; }
+        else if (sf == 1) { hdr = 2; if (size < 2) return ERR_DATA; regen = (zstd_u8(src, 0) >> 4) | (zstd_u8(src, 1) << 4); }
+        else { hdr = 3; if (size < 3) return ERR_DATA; regen = (zstd_u8(src, 0) >> 4) | (zstd_u8(src, 1) << 4) | (zstd_u8(src, 2) << 12); }
     } else {
         if (size < 5) { if (size < 3 || sf >= 2) return ERR_DATA; }
-        const uint64_t v = (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)(size > 3 ? src[3] : 0) << 24) | ((uint64_t)(size > 4 ? src[4] : 0) << 32);
+        const uint64_t v = (uint64_t)zstd_u8(src, 0) | ((uint64_t)zstd_u8(src, 1) << 8) | ((uint64_t)zstd_u8(src, 2) << 16) | ((uint64_t)(size > 3 ? zstd_u8(src, 3) : 0) << 24) | ((uint64_t)(size > 4 ? zstd_u8(src, 4) : 0) << 32);
         if (sf == 0 || sf == 1) { hdr = 3; regen = (int)((v >> 4) & 0x3FF); comp = (int)((v >> 14) & 0x3FF); streams = sf == 0 ? 1 : 4; }
         else if (sf == 2) { hdr = 4; regen = (int)((v >> 4) & 0x3FFF); comp = (int)((v >> 18) & 0x3FFF); streams = 4; }
         else { hdr = 5; regen = (int)((v >> 4) & 0x3FFFF); comp = (int)((v >> 22) & 0x3FFFF); streams = 4; }
@@ -304,7 +309,7 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
         pos += regen;
     } else if (ltype == 1) {
         if (pos + 1 > size) return ERR_DATA;
-        zstd_fill(w->lit, src[pos], regen);
+        zstd_fill(w->lit, zstd_u8(src, pos), regen);
         pos += 1;
     } else {
         if (pos + comp > size) return ERR_DATA;
@@ -320,7 +325,7 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
             if (rc < 0) return rc;
         } else {
             if (lsz < 6) return ERR_DATA;
-            const int s1 = ls[0] | (ls[1] << 8), s2 = ls[2] | (ls[3] << 8), s3 = ls[4] | (ls[5] << 8);
+            const int s1 = zstd_u8(ls, 0) | (zstd_u8(ls, 1) << 8), s2 = zstd_u8(ls, 2) | (zstd_u8(ls, 3) << 8), s3 = zstd_u8(ls, 4) | (zstd_u8(ls, 5) << 8);
             const int s4 = lsz - 6 - s1 - s2 - s3;
             if (s4 < 1) return ERR_DATA;
             const int per = (regen + 3) / 4;
@@ -335,15 +340,15 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
     }
     // ---- sequences section
     if (pos >= size) return ERR_DATA;
-    int nseq = src[pos++];
+    int nseq = zstd_u8(src, pos++);
     if (nseq >= 128) {
-        if (nseq == 255) { if (pos + 2 > size) return ERR_DATA; nseq = src[pos] + (src[pos + 1] << 8) + 0x7F00; pos += 2; }
-        else { if (pos + 1 > size) return ERR_DATA; nseq = ((nseq - 128) << 8) + src[pos++]; }
+        if (nseq == 255) { if (pos + 2 > size) return ERR_DATA; nseq = zstd_u8(src, pos) + (zstd_u8(src, pos + 1) << 8) + 0x7F00; pos += 2; }
+        else { if (pos + 1 > size) return ERR_DATA; nseq = ((nseq - 128) << 8) + zstd_u8(src, pos++); }
     }
     int lpos = 0;                                          // literals consumed
     if (nseq > 0) {
         if (pos >= size) return ERR_DATA;
-        const int modes = src[pos++];
+        const int modes = zstd_u8(src, pos++);
         if (modes & 3) return ERR_DATA;
         for (int k = 0; k < 3; k++) {
             const int mode = (modes >> (6 - 2 * k)) & 3;
@@ -358,8 +363,8 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
                 if (rc < 0) return rc;
             } else if (mode == 1) {
                 if (pos >= size) return ERR_DATA;
-                if (src[pos] > maxsym) return ERR_DATA;
-                zstd_fse_rle(t, src[pos++]);
+                if (zstd_u8(src, pos) > maxsym) return ERR_DATA;
+                zstd_fse_rle(t, zstd_u8(src, pos++));
                 *lg = 0;
             } else if (mode == 2) {
                 int nsym = 0;
@@ -373,13 +378,17 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
         }
         const uint8_t* bs = src + pos;
         const int bl = size - pos;
-        if (bl < 1 || bs[bl - 1] == 0) return ERR_DATA;
-        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(bs[bl - 1]));
+        if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
+        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1)));
         const int llm = (1 << w->ll_log) - 1, ofm = (1 << w->of_log) - 1, mlm = (1 << w->ml_log) - 1;
         int sl = (int)zstd_rbits(bs, bl, &off, w->ll_log), so = (int)zstd_rbits(bs, bl, &off, w->of_log), sm = (int)zstd_rbits(bs, bl, &off, w->ml_log);
         int r0 = fs->r0, r1 = fs->r1, r2 = fs->r2;
         for (int i = 0; i < nseq; i++) {
-            const ZstdFseEntry el = w->ll[sl & llm], eo = w->of[so & ofm], em = w->ml[sm & mlm];
+            ZstdFseEntry el = w->ll[sl & llm], eo = w->of[so & ofm], em = w->ml[sm & mlm];
+            // (every lane loads the same entries: say so, and the loop's control flow and addresses stay on the scalar unit)
+            el.sym = (uint8_t)uni((uint32_t)el.sym); el.nb = (uint8_t)uni((uint32_t)el.nb); el.base = (uint16_t)uni((uint32_t)el.base);
+            eo.sym = (uint8_t)uni((uint32_t)eo.sym); eo.nb = (uint8_t)uni((uint32_t)eo.nb); eo.base = (uint16_t)uni((uint32_t)eo.base);
+            em.sym = (uint8_t)uni((uint32_t)em.sym); em.nb = (uint8_t)uni((uint32_t)em.nb); em.base = (uint16_t)uni((uint32_t)em.base);
             if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
             const uint32_t ov = (1u << eo.sym) + zstd_rbits(bs, bl, &off, eo.sym);
             const int mlen = zstd_ml_base(em.sym) + (int)zstd_rbits(bs, bl, &off, zstd_ml_bits(em.sym));
@@ -416,11 +425,11 @@ CIMG_HD int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int
 }
 
 // One frame at src[0, size) -> dst[0, cap).  Returns the regenerated size or a negative blosc2 error code.
-CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int cap, ZstdWork* w)
+CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int cap, ZstdWork* w)
 {
     if (size < 6) return ERR_DATA;
-    if (!(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) return ERR_DATA;
-    const int fhd = src[4];
+    if (!(zstd_u8(src, 0) == 0x28 && zstd_u8(src, 1) == 0xB5 && zstd_u8(src, 2) == 0x2F && zstd_u8(src, 3) == 0xFD)) return ERR_DATA;
+    const int fhd = zstd_u8(src, 4);
     const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
     if (fhd & 0x08) return ERR_DATA;
     if (did) return ERR_CODEC_SUPPORT;                      // dictionaries: blosc2 does not use them
@@ -430,7 +439,7 @@ CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int ca
     int64_t fcs = -1;
     if (fcs_bytes) {
         fcs = 0;
-        for (int k = 0; k < fcs_bytes && k < 8; k++) fcs |= (int64_t)src[pos + k] << (8 * k);
+        for (int k = 0; k < fcs_bytes && k < 8; k++) fcs |= (int64_t)zstd_u8(src, pos + k) << (8 * k);
         if (fcs_bytes == 2) fcs += 256;
         if (fcs > cap) return ERR_WRITE_BUFFER;
     }
@@ -441,7 +450,7 @@ CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int ca
     int dpos = 0;
     for (int guard = 0; guard <= size; ++guard) {
         if (pos + 3 > size) return ERR_DATA;
-        const int bh = src[pos] | (src[pos + 1] << 8) | (src[pos + 2] << 16);
+        const int bh = zstd_u8(src, pos) | (zstd_u8(src, pos + 1) << 8) | (zstd_u8(src, pos + 2) << 16);
         pos += 3;
         const int last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
         if (type == 0) {
@@ -450,7 +459,7 @@ CIMG_HD int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int ca
             dpos += bsz; pos += bsz;
         } else if (type == 1) {
             if (pos + 1 > size || bsz > cap - dpos) return ERR_DATA;
-            zstd_fill(dst + dpos, src[pos], bsz);
+            zstd_fill(dst + dpos, zstd_u8(src, pos), bsz);
             dpos += bsz; pos += 1;
         } else if (type == 2) {
             if (pos + bsz > size) return ERR_DATA;

@@ -4,8 +4,8 @@
 // The engine launches this kernel only behind a batch in which cimg_decode_blocks reported ERR_CODEC_SUPPORT for some chunk
 // (engine.hip: decompress_finish).  A block of any other chunk is left alone; a chunk with a codec format that no kernel
 // reads (zlib, user codecs) gets ERR_CODEC_SUPPORT again.  LDS: the block's streams decoded back to back, the literal buffer
-// of the frame being decoded, the entropy tables (zstd_decode.h: ZstdWork) and a copy of the frame itself (108 KiB: one block
-// per CU).  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
+// of the frame being decoded -- which for streams of half a block or less shares its area with a copy of the frame --, the
+// entropy tables (zstd_decode.h: ZstdWork): 76 KiB, two blocks per CU.  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
 // un-shuffle at the end is the only lane-parallel part.
 #pragma once
 #include "decode_kernel.h"
@@ -15,7 +15,7 @@ namespace cimg {
 
 enum : int { ZSTD_KERNEL_BLOCK_MAX = 32768 };
 CIMG_HD int zstd_work_bytes() { return (int)((sizeof(ZstdWork) + 15) & ~(size_t)15); }
-// the block's planes | the literal buffer | the entropy tables | the frame being decoded (copied in: the decoder reads it bit by bit)
+// the block's planes | the literal buffer (its upper half: a copy of the frame, for streams of half a block or less) | the entropy tables
 CIMG_HD int zstd_kernel_lds_bytes() { return 2 * ZSTD_KERNEL_BLOCK_MAX + zstd_work_bytes() + 64; }
 
 struct DecodeZstdBlock {
@@ -54,8 +54,13 @@ struct DecodeZstdBlock {
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { fail(chunk, ERR_DATA); return; }
         ZstdWork* w = reinterpret_cast<ZstdWork*>(lds + 2 * ZSTD_KERNEL_BLOCK_MAX);
+        // streams of at most half a block (the split planes of a 2- or 4-byte type): the literal buffer needs only half of its
+        // area and the frame is copied into the other half -- the decoder reads it bit by bit, and an LDS read is a fifth of
+        // a global one.  A stream as large as the block keeps the whole literal area; its frame is read where it lies.
+        const bool staged = neblock <= ZSTD_KERNEL_BLOCK_MAX / 2;
+        uint8_t* stage = lds + ZSTD_KERNEL_BLOCK_MAX + ZSTD_KERNEL_BLOCK_MAX / 2;
         w->lit = lds + ZSTD_KERNEL_BLOCK_MAX;
-        w->lit_cap = ZSTD_KERNEL_BLOCK_MAX;
+        w->lit_cap = staged ? ZSTD_KERNEL_BLOCK_MAX / 2 : ZSTD_KERNEL_BLOCK_MAX;
         int pos = bstart;
         for (int s = 0; s < ns; s++) {
             if (cbytes - pos < 4) { fail(chunk, ERR_READ_BUFFER); return; }
@@ -73,7 +78,8 @@ struct DecodeZstdBlock {
             } else if (cs > neblock) {
                 fail(chunk, ERR_DATA); return;
             } else {
-                const int r = zstd_decode_frame(c + pos, cs, plane, neblock, w);
+                if (staged) zstd_copy(stage, c + pos, cs);           // cs < neblock <= half a block
+                const int r = zstd_decode_frame(staged ? stage : c + pos, cs, plane, neblock, w);
                 if (r != neblock) { fail(chunk, r < 0 ? r : ERR_DATA); return; }
             }
             pos += payload;

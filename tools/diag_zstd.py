@@ -24,6 +24,27 @@ for fam, clevel in (("tiled", 3), ("tiled", 9), ("natural", 3)):
     t0 = time.perf_counter()
     for _ in range(3): eng.decompress_host(chunks)
     dt = (time.perf_counter() - t0) / 3
+    # device-resident: the kernels alone (HIP events of the engine; the zstd launch is a decode launch of its own)
+    sizes = [len(c) for c in chunks]
+    coff = np.concatenate([[0], np.cumsum([(n + 63) & ~63 for n in sizes[:-1]])]).astype(np.int64)
+    blob = np.zeros(int(coff[-1]) + sizes[-1] + 64, np.uint8)
+    for o, c in zip(coff, chunks): blob[o:o + len(c)] = np.frombuffer(c, np.uint8)
+    d_comp, d_out = eng.alloc(blob.size), eng.alloc(host.size)
+    d_comp.upload(blob)
+    nb = [chunk] * len(chunks); roff = np.arange(len(chunks), dtype=np.int64) * chunk
+    eng.decompress_device(d_comp.ptr, coff, nb, [32768] * len(chunks), d_out.ptr, roff)
+    eng.enable_timing(True); eng.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(3): eng.decompress_device(d_comp.ptr, coff, nb, [32768] * len(chunks), d_out.ptr, roff)
+    wall = (time.perf_counter() - t0) / 3
+    ms, k = eng.kernel_time(3)
+    eng.enable_timing(False)
+    print("   device-resident: wall %.1f ms per batch; decode kernels %.1f ms per batch over %d timed launches" % (wall * 1e3, ms / 3, k))
+    lz = eng.compress_host(hip.cparams(2), host, [chunk] * len(chunks), [chunk + 32] * len(chunks))
+    eng.decompress_host(lz)
+    t0 = time.perf_counter()
+    for _ in range(3): eng.decompress_host(lz)
+    print("   the same pixels as lz4 chunks through the same host call: %.1f ms" % ((time.perf_counter() - t0) / 3 * 1e3))
     print("%s clevel %d (%s): %d chunks, ratio %.2f; libzstd compress (python loop, 1 thread) %.2f s; GPU decode incl. PCIe %.1f ms = %.2f GB/s"
           % (fam, clevel, "split planes" if clevel <= 5 else "one stream per block", len(chunks), host.size / csize, t_enc, dt * 1e3, host.size / dt / 1e9))
 os._exit(0)
