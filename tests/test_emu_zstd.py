@@ -76,3 +76,31 @@ def test_a_damaged_zstd_chunk_reports_an_error_and_leaves_its_neighbours_alone(k
     rc, status, out = E.decompress_batch([good.tobytes(), bad.tobytes(), good.tobytes()], [src.size] * 3, [bs] * 3)
     assert status[0] == 0 and status[2] == 0 and status[1] < 0
     assert out[0].tobytes() == src.tobytes() and out[2].tobytes() == src.tobytes()
+
+
+def test_chunks_made_with_the_local_libzstd(golden_dir):
+    """Beyond the committed vectors: every element size, split and unsplit, ragged last block -- made here with the system
+    libzstd (skipped where there is none), decoded by the emulated kernels."""
+    import ctypes as C
+    import ctypes.util
+    import sys
+    name = ctypes.util.find_library("zstd")
+    if not name:
+        pytest.skip("no libzstd here")
+    sys.path.insert(0, golden_dir)
+    import make_zstd_golden as G
+    from cimg import synth
+    z = C.CDLL(name)
+    z.ZSTD_compressBound.restype = C.c_size_t; z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t; z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    z.ZSTD_isError.argtypes = [C.c_size_t]
+    for dtype, fam in ((np.uint8, synth.natural_channel), (np.uint16, synth.tiled_channel), (np.float16, synth.natural_channel),
+                       (np.float32, synth.tiled_channel), (np.float32, synth.natural_channel)):
+        it = np.dtype(dtype).itemsize
+        a = fam(dtype, 512, 256 // it + 3)
+        src = np.ascontiguousarray(a).view(np.uint8).ravel()
+        for clevel in (1, 5, 9):
+            chunk = G.frame(z, src, it, 32768, clevel)
+            rc, status, out = E.decompress_batch([chunk], [src.size], [32768])
+            assert rc == 0 and status == [0], (dtype, clevel, status)
+            assert out[0].tobytes() == src.tobytes(), (dtype, clevel)

@@ -7,6 +7,7 @@ configs[1] geometry at full size.  Run on the GPU box:  python -m pytest tests -
 import ctypes as C
 import os
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -765,3 +766,33 @@ def test_zstd_chunks_decode_on_the_gpu(eng, golden_dir):
         assert L.blosc2_decompress_ctx(dctx, buf.ctypes.data, buf.size, out.ctypes.data, out.size) == want.size, n
         assert out.tobytes() == want.tobytes(), n
     L.blosc2_free_ctx(dctx)
+
+
+def test_zstd_chunks_made_on_this_box(eng, golden_dir):
+    """Beyond the committed vectors: chunks of every element size, split and unsplit, made here with the box's own libzstd
+    (skipped where there is none) and framed as c-blosc2 frames them (tests/golden/make_zstd_golden.py) -- 1 MiB each, ragged
+    last block included -- decode to their pixels."""
+    import ctypes as C
+    import ctypes.util
+    name = ctypes.util.find_library("zstd")
+    if not name:
+        pytest.skip("no libzstd on this box")
+    sys.path.insert(0, golden_dir)
+    import make_zstd_golden as G
+    z = C.CDLL(name)
+    z.ZSTD_compressBound.restype = C.c_size_t; z.ZSTD_compressBound.argtypes = [C.c_size_t]
+    z.ZSTD_compress.restype = C.c_size_t; z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    z.ZSTD_isError.argtypes = [C.c_size_t]
+    chunks, want = [], []
+    for dtype, fam in ((np.uint8, synth.natural_channel), (np.uint16, synth.tiled_channel), (np.float16, synth.natural_channel),
+                       (np.float32, synth.tiled_channel), (np.float32, synth.natural_channel)):
+        it = np.dtype(dtype).itemsize
+        a = fam(dtype, 1024, 1024 // it + 3)                       # a little over 1 MiB: the last block is a leftover
+        src = np.ascontiguousarray(a).view(np.uint8).ravel()
+        for clevel in (1, 5, 9):
+            chunks.append(G.frame(z, src, it, 32768, clevel))
+            want.append(src)
+    outs, status = eng.decompress_host(chunks)
+    assert not status.any()
+    for k, (o, w) in enumerate(zip(outs, want)):
+        assert o.tobytes() == w.tobytes(), k
