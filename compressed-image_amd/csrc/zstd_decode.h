@@ -63,6 +63,34 @@ CIMG_DEV uint32_t zstd_rbits(const uint8_t* src, int size, int64_t* off, int n)
     if (miss >= n) return 0;
     return zstd_bits(src, size, 0, (int)(n - miss)) << miss;
 }
+// The backward reader of the entropy loops: `off` as above, with the 64 bits around it kept in a register -- one 8-byte load per
+// ~ 30 bits consumed instead of one per read.  Near the start of the stream (and for streams shorter than 8 bytes) it falls
+// back on zstd_rbits, which knows about the zero bits below position 0.
+struct ZstdBack {
+    const uint8_t* src;
+    int size;
+    int64_t off, lo;                                   // cont holds bits [lo, lo + 64); lo < 0: nothing loaded yet
+    uint64_t cont;
+    CIMG_DEV void init(const uint8_t* s, int n, int64_t o) { src = s; size = n; off = o; lo = -1; cont = 0; }
+    CIMG_DEV uint32_t get(int n)
+    {
+        if (n <= 0) return 0;
+        const int64_t t = off - n;
+        if (size >= 8 && t >= 0) {
+            if (lo < 0 || t < lo) {
+                const int64_t b = ((off + 7) >> 3) - 8;
+                lo = 8 * (b > 0 ? b : 0);
+                uint64_t c;
+                memcpy(&c, src + (lo >> 3), 8);
+                cont = (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
+            }
+            off = t;
+            return (uint32_t)((cont >> (t - lo)) & ((1ull << n) - 1));
+        }
+        return zstd_rbits(src, size, &off, n);
+    }
+};
+
 // a byte every lane reads from the same address: wave-uniform, and said so (the decoder's control flow then stays scalar)
 CIMG_DEV int zstd_u8(const uint8_t* p, int i) { return (int)uni((uint32_t)p[i]); }
 CIMG_DEV int zstd_highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
@@ -198,17 +226,18 @@ CIMG_DEV int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
         const uint8_t* bs = f + h;
         const int bl = hb - h;
         if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
-        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1)));
+        ZstdBack br;
+        br.init(bs, bl, (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1))));
         const int mask = (1 << log) - 1;
-        int s1 = (int)zstd_rbits(bs, bl, &off, log), s2 = (int)zstd_rbits(bs, bl, &off, log);
+        int s1 = (int)br.get(log), s2 = (int)br.get(log);
         for (;;) {
             if (n >= 254) return ERR_DATA;
             w->weights[n++] = w->wt[s1 & mask].sym;
-            s1 = uni((int)w->wt[s1 & mask].base) + (int)zstd_rbits(bs, bl, &off, uni((int)w->wt[s1 & mask].nb));
-            if (off < 0) { w->weights[n++] = w->wt[s2 & mask].sym; break; }
+            s1 = uni((int)w->wt[s1 & mask].base) + (int)br.get(uni((int)w->wt[s1 & mask].nb));
+            if (br.off < 0) { w->weights[n++] = w->wt[s2 & mask].sym; break; }
             w->weights[n++] = w->wt[s2 & mask].sym;
-            s2 = uni((int)w->wt[s2 & mask].base) + (int)zstd_rbits(bs, bl, &off, uni((int)w->wt[s2 & mask].nb));
-            if (off < 0) { w->weights[n++] = w->wt[s1 & mask].sym; break; }
+            s2 = uni((int)w->wt[s2 & mask].base) + (int)br.get(uni((int)w->wt[s2 & mask].nb));
+            if (br.off < 0) { w->weights[n++] = w->wt[s1 & mask].sym; break; }
         }
         used = 1 + hb;
     }
@@ -246,16 +275,17 @@ CIMG_DEV int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int cou
 {
     if (size < 1 || zstd_u8(src, size - 1) == 0) return ERR_DATA;
     const int log = w->huf_log, mask = (1 << log) - 1;
-    int64_t off = (int64_t)size * 8 - (8 - zstd_highbit(zstd_u8(src, size - 1)));
-    int state = (int)zstd_rbits(src, size, &off, log);
+    ZstdBack br;
+    br.init(src, size, (int64_t)size * 8 - (8 - zstd_highbit(zstd_u8(src, size - 1))));
+    int state = (int)br.get(log);
     int n = 0;
-    while (off > -log) {
+    while (br.off > -log) {
         if (n >= count) return ERR_DATA;
         out[n++] = w->huf_sym[state & mask];
         const int nb = (int)uni((uint32_t)w->huf_nb[state & mask]);
-        state = ((state << nb) + (int)zstd_rbits(src, size, &off, nb)) & mask;
+        state = ((state << nb) + (int)br.get(nb)) & mask;
     }
-    return (off == -log && n == count) ? 0 : ERR_DATA;
+    return (br.off == -log && n == count) ? 0 : ERR_DATA;
 }
 
 // ---- byte movers: the only lane-parallel part of the decoder (64 bytes per step) -------------------------------------------
@@ -379,9 +409,10 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         const uint8_t* bs = src + pos;
         const int bl = size - pos;
         if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
-        int64_t off = (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1)));
+        ZstdBack br;
+        br.init(bs, bl, (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1))));
         const int llm = (1 << w->ll_log) - 1, ofm = (1 << w->of_log) - 1, mlm = (1 << w->ml_log) - 1;
-        int sl = (int)zstd_rbits(bs, bl, &off, w->ll_log), so = (int)zstd_rbits(bs, bl, &off, w->of_log), sm = (int)zstd_rbits(bs, bl, &off, w->ml_log);
+        int sl = (int)br.get(w->ll_log), so = (int)br.get(w->of_log), sm = (int)br.get(w->ml_log);
         int r0 = fs->r0, r1 = fs->r1, r2 = fs->r2;
         for (int i = 0; i < nseq; i++) {
             ZstdFseEntry el = w->ll[sl & llm], eo = w->of[so & ofm], em = w->ml[sm & mlm];
@@ -390,15 +421,15 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
             eo.sym = (uint8_t)uni((uint32_t)eo.sym); eo.nb = (uint8_t)uni((uint32_t)eo.nb); eo.base = (uint16_t)uni((uint32_t)eo.base);
             em.sym = (uint8_t)uni((uint32_t)em.sym); em.nb = (uint8_t)uni((uint32_t)em.nb); em.base = (uint16_t)uni((uint32_t)em.base);
             if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
-            const uint32_t ov = (1u << eo.sym) + zstd_rbits(bs, bl, &off, eo.sym);
-            const int mlen = zstd_ml_base(em.sym) + (int)zstd_rbits(bs, bl, &off, zstd_ml_bits(em.sym));
-            const int llen = zstd_ll_base(el.sym) + (int)zstd_rbits(bs, bl, &off, zstd_ll_bits(el.sym));
+            const uint32_t ov = (1u << eo.sym) + br.get(eo.sym);
+            const int mlen = zstd_ml_base(em.sym) + (int)br.get(zstd_ml_bits(em.sym));
+            const int llen = zstd_ll_base(el.sym) + (int)br.get(zstd_ll_bits(el.sym));
             if (i + 1 < nseq) {
-                sl = el.base + (int)zstd_rbits(bs, bl, &off, el.nb);
-                sm = em.base + (int)zstd_rbits(bs, bl, &off, em.nb);
-                so = eo.base + (int)zstd_rbits(bs, bl, &off, eo.nb);
+                sl = el.base + (int)br.get(el.nb);
+                sm = em.base + (int)br.get(em.nb);
+                so = eo.base + (int)br.get(eo.nb);
             }
-            if (off < 0) return ERR_DATA;
+            if (br.off < 0) return ERR_DATA;
             // (three named scalars, no indexing by idx: a dynamically indexed private array is scratch memory on the device)
             int offset;
             if (ov > 3) { offset = (int)(ov - 3); r2 = r1; r1 = r0; r0 = offset; }
@@ -415,7 +446,7 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
             zstd_match(dst + dpos, offset, mlen);
             dpos += mlen;
         }
-        if (off != 0) return ERR_DATA;
+        if (br.off != 0) return ERR_DATA;
         fs->r0 = r0; fs->r1 = r1; fs->r2 = r2;
     }
     const int rest = regen - lpos;
