@@ -66,7 +66,9 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
                                void* d_comp, const int64_t* comp_off, const int32_t* destsize,
                                int32_t* cbytes);
 /* nbytes[i] / blocksize[i] are the values in chunk i's header (blosc2_cbuffer_sizes); status[i]
- * receives 0 or the blosc2 error code of that chunk. Returns the first non-zero status, or 0. */
+ * receives 0 or the blosc2 error code of that chunk. Returns the first non-zero status, or 0.
+ * Chunks of codec format 0 (blosclz), 1 (lz4, lz4hc) and 4 (zstd: a slow path, launched only when such a
+ * chunk is in the batch) decode; any other format is BLOSC2_ERROR_CODEC_SUPPORT for that chunk. */
 int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks,
                                  const void* d_comp, const int64_t* comp_off,
                                  const int32_t* nbytes, const int32_t* blocksize,
