@@ -20,11 +20,11 @@ namespace cimg {
 
 enum : int { ZSTD_LIT_CAP = 65536, ZSTD_HUF_LOG_MAX = 11, ZSTD_FSE_LOG_MAX = 9 };
 
-struct ZstdFseEntry { uint8_t sym, nb; uint16_t base; };
+struct ZstdFseEntry { uint8_t sym, nb; uint16_t base; };      // (read as one little-endian dword in the sequence loop)
+static_assert(sizeof(ZstdFseEntry) == 4, "one dword per entry");
 
 struct ZstdWork {
-    uint8_t huf_sym[1 << ZSTD_HUF_LOG_MAX];
-    uint8_t huf_nb[1 << ZSTD_HUF_LOG_MAX];
+    uint16_t huf[1 << ZSTD_HUF_LOG_MAX];            // symbol | code length << 8: one load per decoded literal
     ZstdFseEntry ll[1 << ZSTD_FSE_LOG_MAX], ml[1 << ZSTD_FSE_LOG_MAX], of[1 << ZSTD_FSE_LOG_MAX], wt[64];
     int16_t freq[256];
     uint16_t sdesc[256];
@@ -263,7 +263,7 @@ CIMG_DEV int zstd_huf_read_tree(const uint8_t* src, int size, ZstdWork* w)
         if (!b) continue;
         const int len = 1 << (maxbits - b), at = uni((int)rank_idx[b]);
         // (the 2^(maxbits - b) entries of a code: 64 per step)
-        for (int k0 = 0; k0 < len; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < len) { w->huf_sym[at + k0 + l] = (uint8_t)i; w->huf_nb[at + k0 + l] = (uint8_t)b; } } }
+        for (int k0 = 0; k0 < len; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < len) w->huf[at + k0 + l] = (uint16_t)(i | (b << 8)); } }
         rank_idx[b] = at + len;
     }
     w->huf_log = maxbits;
@@ -281,8 +281,9 @@ CIMG_DEV int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int cou
     int n = 0;
     while (br.off > -log) {
         if (n >= count) return ERR_DATA;
-        out[n++] = w->huf_sym[state & mask];
-        const int nb = (int)uni((uint32_t)w->huf_nb[state & mask]);
+        const uint32_t e = uni((uint32_t)w->huf[state & mask]);
+        out[n++] = (uint8_t)e;
+        const int nb = (int)(e >> 8);
         state = ((state << nb) + (int)br.get(nb)) & mask;
     }
     return (br.off == -log && n == count) ? 0 : ERR_DATA;
@@ -301,7 +302,7 @@ CIMG_DEV void zstd_fill(uint8_t* dst, uint8_t v, int n)
 // dst[k] = dst[k - offset], k = 0 .. n-1 in order: with offset < 64 the source is the repeating pattern in front of dst
 CIMG_DEV void zstd_match(uint8_t* dst, int offset, int n)
 {
-    if (offset >= 64) {
+    if (offset >= 64 || offset >= n) {                 // (n <= offset: nothing written here is read here)
         // (a step reads [k0 - offset, k0 + 64 - offset), all of it in front of the 64 bytes it writes)
         for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = dst[k0 + l - offset]; } }
         return;
@@ -415,11 +416,15 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         int sl = (int)br.get(w->ll_log), so = (int)br.get(w->of_log), sm = (int)br.get(w->ml_log);
         int r0 = fs->r0, r1 = fs->r1, r2 = fs->r2;
         for (int i = 0; i < nseq; i++) {
-            ZstdFseEntry el = w->ll[sl & llm], eo = w->of[so & ofm], em = w->ml[sm & mlm];
-            // (every lane loads the same entries: say so, and the loop's control flow and addresses stay on the scalar unit)
-            el.sym = (uint8_t)uni((uint32_t)el.sym); el.nb = (uint8_t)uni((uint32_t)el.nb); el.base = (uint16_t)uni((uint32_t)el.base);
-            eo.sym = (uint8_t)uni((uint32_t)eo.sym); eo.nb = (uint8_t)uni((uint32_t)eo.nb); eo.base = (uint16_t)uni((uint32_t)eo.base);
-            em.sym = (uint8_t)uni((uint32_t)em.sym); em.nb = (uint8_t)uni((uint32_t)em.nb); em.base = (uint16_t)uni((uint32_t)em.base);
+            // one 32-bit load per entry, and every lane loads the same three: say so, and the loop's control flow and addresses
+            // stay on the scalar unit
+            uint32_t pl, po, pm;
+            memcpy(&pl, &w->ll[sl & llm], 4); memcpy(&po, &w->of[so & ofm], 4); memcpy(&pm, &w->ml[sm & mlm], 4);
+            pl = uni(pl); po = uni(po); pm = uni(pm);
+            ZstdFseEntry el, eo, em;
+            el.sym = (uint8_t)pl; el.nb = (uint8_t)(pl >> 8); el.base = (uint16_t)(pl >> 16);
+            eo.sym = (uint8_t)po; eo.nb = (uint8_t)(po >> 8); eo.base = (uint16_t)(po >> 16);
+            em.sym = (uint8_t)pm; em.nb = (uint8_t)(pm >> 8); em.base = (uint16_t)(pm >> 16);
             if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
             const uint32_t ov = (1u << eo.sym) + br.get(eo.sym);
             const int mlen = zstd_ml_base(em.sym) + (int)br.get(zstd_ml_bits(em.sym));

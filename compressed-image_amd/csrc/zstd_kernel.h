@@ -74,11 +74,13 @@ struct DecodeZstdBlock {
                 const uint8_t v = (uint8_t)((uint32_t)(-cs) & 0xFF);
                 for (int i = 0; i < neblock; i += 64) { FOR_LANES_W(l) { if (i + l < neblock) plane[i + l] = v; } }
             } else if (cs == neblock) {
-                for (int i = 0; i < neblock; i += 64) { FOR_LANES_W(l) { if (i + l < neblock) plane[i + l] = c[pos + i + l]; } }
+                // stored stream: 16 bytes per lane, eight loads in flight (a byte loop waits for HBM 256 times per plane)
+                if (((s * neblock) & 15) == 0) wave_copy_g2l(c + pos, lds, s * neblock, neblock);
+                else for (int i = 0; i < neblock; i += 64) { FOR_LANES_W(l) { if (i + l < neblock) plane[i + l] = c[pos + i + l]; } }
             } else if (cs > neblock) {
                 fail(chunk, ERR_DATA); return;
             } else {
-                if (staged) zstd_copy(stage, c + pos, cs);           // cs < neblock <= half a block
+                if (staged) wave_copy_g2l(c + pos, lds, ZSTD_KERNEL_BLOCK_MAX + ZSTD_KERNEL_BLOCK_MAX / 2, cs);   // cs < neblock <= half a block
                 const int r = zstd_decode_frame(staged ? stage : c + pos, cs, plane, neblock, w);
                 if (r != neblock) { fail(chunk, r < 0 ? r : ERR_DATA); return; }
             }
@@ -87,6 +89,33 @@ struct DecodeZstdBlock {
         // un-shuffle (blosc's byte shuffle leaves the bsize % ts tail bytes where they were)
         const int ne = bsize / ts;
         const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
+        if (shuf && (ts == 2 || ts == 4) && (bsize & 63) == 0) {
+            // the usual shapes: 16 output bytes per lane and step (the byte merges of decode_lean_kernel.h)
+            const int units = bsize >> 4;
+            for (int u0 = 0; u0 < units; u0 += 64) {
+                FOR_LANES_W(l) {
+                    const int u = u0 + l;
+                    if (u < units) {
+                        u128 o;
+                        if (ts == 2) {
+                            const uint32_t a0 = *reinterpret_cast<const uint32_t*>(lds + 8 * u), a1 = *reinterpret_cast<const uint32_t*>(lds + 8 * u + 4);
+                            const uint32_t b0 = *reinterpret_cast<const uint32_t*>(lds + ne + 8 * u), b1 = *reinterpret_cast<const uint32_t*>(lds + ne + 8 * u + 4);
+                            o.x = byte_perm(b0, a0, 0x05010400u); o.y = byte_perm(b0, a0, 0x07030602u);
+                            o.z = byte_perm(b1, a1, 0x05010400u); o.w = byte_perm(b1, a1, 0x07030602u);
+                        } else {
+                            const uint32_t A = *reinterpret_cast<const uint32_t*>(lds + 4 * u), B = *reinterpret_cast<const uint32_t*>(lds + ne + 4 * u);
+                            const uint32_t Cc = *reinterpret_cast<const uint32_t*>(lds + 2 * ne + 4 * u), D = *reinterpret_cast<const uint32_t*>(lds + 3 * ne + 4 * u);
+                            const uint32_t t0 = byte_perm(B, A, 0x05010400u), t1 = byte_perm(B, A, 0x07030602u);
+                            const uint32_t v0 = byte_perm(D, Cc, 0x05010400u), v1 = byte_perm(D, Cc, 0x07030602u);
+                            o.x = byte_perm(v0, t0, 0x05040100u); o.y = byte_perm(v0, t0, 0x07060302u);
+                            o.z = byte_perm(v1, t1, 0x05040100u); o.w = byte_perm(v1, t1, 0x07060302u);
+                        }
+                        st128u(out + 16 * u, o);
+                    }
+                }
+            }
+            return;
+        }
         for (int i0 = 0; i0 < bsize; i0 += 64) {
             FOR_LANES_W(l) {
                 const int i = i0 + l;
