@@ -481,13 +481,25 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
             eo.sym = (uint8_t)po; eo.nb = (uint8_t)(po >> 8); eo.base = (uint16_t)(po >> 16);
             em.sym = (uint8_t)pm; em.nb = (uint8_t)(pm >> 8); em.base = (uint16_t)(pm >> 16);
             if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
-            const uint32_t ov = (1u << eo.sym) + br.get(eo.sym);
-            const int mlen = zstd_ml_base(em.sym) + (int)br.get(zstd_ml_bits(em.sym));
-            const int llen = zstd_ll_base(el.sym) + (int)br.get(zstd_ll_bits(el.sym));
+            // The extra bits of offset, match length and literal length lie one behind the other in the stream (first read =
+            // highest bits), and so do the three state updates: one read each when they fit 32 bits (they nearly always do)
+            // instead of three.
+            const int xa = eo.sym, xb = zstd_ml_bits(em.sym), xc = zstd_ll_bits(el.sym);
+            uint32_t xo, xm, xl;
+            if (xa + xb + xc <= 32) {
+                const uint32_t V = br.get(xa + xb + xc);
+                xl = V & ((1u << xc) - 1);
+                xm = (V >> xc) & ((1u << xb) - 1);
+                xo = xa ? V >> (xb + xc) : 0;
+            } else { xo = br.get(xa); xm = br.get(xb); xl = br.get(xc); }
+            const uint32_t ov = (1u << eo.sym) + xo;
+            const int mlen = zstd_ml_base(em.sym) + (int)xm;
+            const int llen = zstd_ll_base(el.sym) + (int)xl;
             if (i + 1 < nseq) {
-                sl = el.base + (int)br.get(el.nb);
-                sm = em.base + (int)br.get(em.nb);
-                so = eo.base + (int)br.get(eo.nb);
+                const uint32_t V = br.get(el.nb + em.nb + eo.nb);              // <= 9 + 9 + 8 bits
+                so = eo.base + (int)(V & ((1u << eo.nb) - 1));
+                sm = em.base + (int)((V >> eo.nb) & ((1u << em.nb) - 1));
+                sl = el.base + (int)(V >> (eo.nb + em.nb));
             }
             if (br.off < 0) return ERR_DATA;
             // (three named scalars, no indexing by idx: a dynamically indexed private array is scratch memory on the device)
