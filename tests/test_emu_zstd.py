@@ -104,3 +104,32 @@ def test_chunks_made_with_the_local_libzstd(golden_dir):
             rc, status, out = E.decompress_batch([chunk], [src.size], [32768])
             assert rc == 0 and status == [0], (dtype, clevel, status)
             assert out[0].tobytes() == src.tobytes(), (dtype, clevel)
+
+
+def test_zstd_chunks_through_the_reference_entry_point_on_the_mock_library(kat):
+    """blosc2_decompress_ctx of tests/emu/libcimg_hip_mock.so (the C ABI served by the emulator): the call the reference makes
+    per chunk (blosc2/wrapper.h:236-259) reads zstd chunks -- shim -> batch call -> general kernel -> zstd kernel."""
+    import ctypes as C
+    from cimg import hip
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "libcimg_hip_mock.so")
+    if not os.path.exists(path):
+        pytest.skip("mock C ABI not built (python -c 'import __graft_entry__ as g; g.build()')")
+    L = C.CDLL(path)
+    L.blosc2_create_dctx.restype = C.c_void_p
+    L.blosc2_create_dctx.argtypes = [hip.Blosc2DParams]
+    L.blosc2_decompress_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    L.blosc2_free_ctx.argtypes = [C.c_void_p]
+    dp = hip.Blosc2DParams()
+    dp.nthreads = 1
+    d = L.blosc2_create_dctx(dp)
+    try:
+        for n in kat["chunks"]:
+            n = str(n)
+            c = kat["chunk|" + n].copy()
+            want = kat["cin|" + n]
+            out = np.zeros(want.size, np.uint8)
+            assert L.blosc2_decompress_ctx(d, c.ctypes.data, c.size, out.ctypes.data, out.size) == want.size, n
+            assert out.tobytes() == want.tobytes(), n
+            assert L.blosc2_decompress_ctx(d, c.ctypes.data, c.size, out.ctypes.data, out.size - 1) < 0
+    finally:
+        L.blosc2_free_ctx(d)
