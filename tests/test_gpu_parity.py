@@ -796,3 +796,23 @@ def test_zstd_chunks_made_on_this_box(eng, golden_dir):
     assert not status.any()
     for k, (o, w) in enumerate(zip(outs, want)):
         assert o.tobytes() == w.tobytes(), k
+
+
+def test_mutated_zstd_chunks_fail_or_decode_but_never_hang(eng, golden_dir):
+    """240 bit-flipped copies of the golden zstd chunks in batches of 60: every chunk ends with a status (0 = the flip hit
+    bytes that do not matter, or a stored stream; < 0 = rejected), the undamaged chunk riding along in each batch still decodes."""
+    kat = np.load(os.path.join(golden_dir, "zstd_kat.npz"))
+    rng = np.random.default_rng(99)
+    names = [str(n) for n in kat["chunks"]]
+    good = kat["chunk|" + names[0]].tobytes()
+    want = kat["cin|" + names[0]].tobytes()
+    for rnd in range(4):
+        batch = [good]
+        for k in range(60):
+            c = bytearray(kat["chunk|" + names[(rnd + k) % len(names)]].tobytes())
+            for _ in range(1 + k % 3):
+                c[int(rng.integers(32, len(c)))] ^= 1 << int(rng.integers(0, 8))
+            batch.append(bytes(c))
+        outs, status = eng.decompress_host(batch, check=False)
+        assert status[0] == 0 and outs[0].tobytes() == want
+        assert (status <= 0).all()
