@@ -6,7 +6,7 @@
 // reads (zlib, user codecs) gets ERR_CODEC_SUPPORT again.  LDS: the block's streams decoded back to back, the literal buffer
 // of the frame being decoded -- which for streams of half a block or less shares its area with a copy of the frame --, the
 // entropy tables (zstd_decode.h: ZstdWork): 76 KiB, two blocks per CU.  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
-// un-shuffle at the end is the only lane-parallel part.
+// filter stage at the end (the general kernel's) and the byte movers are the lane-parallel parts.
 #pragma once
 #include "decode_kernel.h"
 #include "zstd_decode.h"
@@ -45,7 +45,8 @@ struct DecodeZstdBlock {
         if (fmt == 0 || fmt == 1) return;
         if (fmt != 4) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         const int filter = (int)((f1 >> 8) & 0xFF);
-        if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE)) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE)) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) { fail(chunk, ERR_CODEC_SUPPORT); return; }          // bit rows are never split
         if (blocksize > ZSTD_KERNEL_BLOCK_MAX || zstd_kernel_lds_bytes() > a.lds_bytes) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         const bool leftover_blk = bsize != blocksize;
         const int ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
@@ -86,42 +87,13 @@ struct DecodeZstdBlock {
             }
             pos += payload;
         }
-        // un-shuffle (blosc's byte shuffle leaves the bsize % ts tail bytes where they were)
-        const int ne = bsize / ts;
-        const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
-        if (shuf && (ts == 2 || ts == 4) && (bsize & 63) == 0) {
-            // the usual shapes: 16 output bytes per lane and step (the byte merges of decode_lean_kernel.h)
-            const int units = bsize >> 4;
-            for (int u0 = 0; u0 < units; u0 += 64) {
-                FOR_LANES_W(l) {
-                    const int u = u0 + l;
-                    if (u < units) {
-                        u128 o;
-                        if (ts == 2) {
-                            const uint32_t a0 = *reinterpret_cast<const uint32_t*>(lds + 8 * u), a1 = *reinterpret_cast<const uint32_t*>(lds + 8 * u + 4);
-                            const uint32_t b0 = *reinterpret_cast<const uint32_t*>(lds + ne + 8 * u), b1 = *reinterpret_cast<const uint32_t*>(lds + ne + 8 * u + 4);
-                            o.x = byte_perm(b0, a0, 0x05010400u); o.y = byte_perm(b0, a0, 0x07030602u);
-                            o.z = byte_perm(b1, a1, 0x05010400u); o.w = byte_perm(b1, a1, 0x07030602u);
-                        } else {
-                            const uint32_t A = *reinterpret_cast<const uint32_t*>(lds + 4 * u), B = *reinterpret_cast<const uint32_t*>(lds + ne + 4 * u);
-                            const uint32_t Cc = *reinterpret_cast<const uint32_t*>(lds + 2 * ne + 4 * u), D = *reinterpret_cast<const uint32_t*>(lds + 3 * ne + 4 * u);
-                            const uint32_t t0 = byte_perm(B, A, 0x05010400u), t1 = byte_perm(B, A, 0x07030602u);
-                            const uint32_t v0 = byte_perm(D, Cc, 0x05010400u), v1 = byte_perm(D, Cc, 0x07030602u);
-                            o.x = byte_perm(v0, t0, 0x05040100u); o.y = byte_perm(v0, t0, 0x07060302u);
-                            o.z = byte_perm(v1, t1, 0x05040100u); o.w = byte_perm(v1, t1, 0x07060302u);
-                        }
-                        st128u(out + 16 * u, o);
-                    }
-                }
-            }
-            return;
-        }
-        for (int i0 = 0; i0 < bsize; i0 += 64) {
-            FOR_LANES_W(l) {
-                const int i = i0 + l;
-                if (i < bsize) out[i] = (shuf && i < ne * ts) ? lds[(i % ts) * ne + i / ts] : lds[i];
-            }
-        }
+        // the filter stage is the general kernel's own (decode_kernel.h: DecodeBlock::phase_b -- byte shuffle for every element
+        // size, bit shuffle, none): the planes lie back to back here, i.e. its region stride is the plane size, and its four
+        // waves' shares are walked one after the other by this one
+        DecodeBlock fb(a, lds, b);
+        fb.chunk = chunk; fb.j = j; fb.bsize = bsize; fb.ns = ns; fb.neblock = neblock; fb.rs = neblock; fb.ts = ts;
+        fb.filter = filter; fb.mode = 0; fb.c = c; fb.out = out;
+        for (int wv = 0; wv < 4; ++wv) fb.phase_b(wv);
     }
 
     CIMG_DEV void fail(int chunk, int code) { FOR_LANES_W(l) { if (l == 0) a.status[chunk] = code; } }

@@ -37,7 +37,15 @@ def shuffle(ts, blk):
     return out
 
 
-def frame(z, src, ts, blocksize, clevel):
+def bitshuffle(ts, blk):
+    """blosc2's bit shuffle of one block, through the oracle's restatement (tests/_oracle.py; only the on-the-fly tests use it)."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import _oracle as O
+    return np.asarray(O.bitshuffle(ts, blk), np.uint8).copy()
+
+
+def frame(z, src, ts, blocksize, clevel, filt="shuffle"):
+    """filt: "shuffle" (what the reference sets), "bitshuffle" (one stream per block, as c-blosc2 does for bit rows) or "none"."""
     nbytes = src.size
     nblocks = -(-nbytes // blocksize)
     level = 2 * clevel - 1 if clevel < 9 else z.ZSTD_maxCLevel()
@@ -46,10 +54,10 @@ def frame(z, src, ts, blocksize, clevel):
     body = b""
     bstarts = []
     base = 32 + 4 * nblocks
-    split_chunk = clevel <= 5 and ts > 1
+    split_chunk = clevel <= 5 and ts > 1 and filt == "shuffle"
     for j in range(nblocks):
         blk = src[j * blocksize:(j + 1) * blocksize]
-        f = shuffle(ts, blk)
+        f = shuffle(ts, blk) if filt == "shuffle" else (bitshuffle(ts, blk) if filt == "bitshuffle" else blk)
         bstarts.append(base + len(body))
         leftover = blk.size != blocksize
         ns = ts if (split_chunk and not leftover and blk.size % ts == 0) else 1
@@ -67,7 +75,7 @@ def frame(z, src, ts, blocksize, clevel):
                 body += struct.pack("<i", out.size) + out.tobytes()
     cbytes = base + len(body)
     flags = 0x01 | 0x04 | (0 if split_chunk else 0x10) | (4 << 5)
-    hdr = struct.pack("<BBBBiii", 5, 1, flags, ts, nbytes, blocksize, cbytes) + bytes([0, 0, 0, 0, 0, 1]) + bytes([5, 0]) + bytes(8)
+    hdr = struct.pack("<BBBBiii", 5, 1, flags, ts, nbytes, blocksize, cbytes) + bytes([0, 0, 0, 0, 0, {"shuffle": 1, "bitshuffle": 2, "none": 0}[filt]]) + bytes([5, 0]) + bytes(8)
     assert len(hdr) == 32
     return hdr + struct.pack(f"<{nblocks}i", *bstarts) + body
 

@@ -100,10 +100,11 @@ def test_chunks_made_with_the_local_libzstd(golden_dir):
         a = fam(dtype, 512, 256 // it + 3)
         src = np.ascontiguousarray(a).view(np.uint8).ravel()
         for clevel in (1, 5, 9):
-            chunk = G.frame(z, src, it, 32768, clevel)
-            rc, status, out = E.decompress_batch([chunk], [src.size], [32768])
-            assert rc == 0 and status == [0], (dtype, clevel, status)
-            assert out[0].tobytes() == src.tobytes(), (dtype, clevel)
+            for filt in ("shuffle", "bitshuffle", "none"):
+                chunk = G.frame(z, src, it, 32768, clevel, filt)
+                rc, status, out = E.decompress_batch([chunk], [src.size], [32768])
+                assert rc == 0 and status == [0], (dtype, clevel, filt, status)
+                assert out[0].tobytes() == src.tobytes(), (dtype, clevel, filt)
 
 
 def test_zstd_chunks_through_the_reference_entry_point_on_the_mock_library(kat):

@@ -790,8 +790,9 @@ def test_zstd_chunks_made_on_this_box(eng, golden_dir):
         a = fam(dtype, 1024, 1024 // it + 3)                       # a little over 1 MiB: the last block is a leftover
         src = np.ascontiguousarray(a).view(np.uint8).ravel()
         for clevel in (1, 5, 9):
-            chunks.append(G.frame(z, src, it, 32768, clevel))
-            want.append(src)
+            for filt in ("shuffle", "bitshuffle", "none"):
+                chunks.append(G.frame(z, src, it, 32768, clevel, filt))
+                want.append(src)
     outs, status = eng.decompress_host(chunks)
     assert not status.any()
     for k, (o, w) in enumerate(zip(outs, want)):
