@@ -236,7 +236,7 @@ struct cimg_engine {
     // a decode batch between decompress_launch() and decompress_finish()
     struct DecodeFlight {
         bool lean = false, general_now = true, timed = false;
-        int32_t nchunks = 0, total_blocks = 0, lds_bytes = 0;
+        int32_t nchunks = 0, total_blocks = 0, lds_bytes = 0, max_blocksize = 0;
         size_t st_bytes = 0;
         DecodeArgs da{};
     } dflight;
@@ -771,6 +771,8 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     e->dflight.lean = lean; e->dflight.general_now = general_now; e->dflight.timed = timed;
     e->dflight.nchunks = nchunks; e->dflight.total_blocks = plan.total_blocks; e->dflight.lds_bytes = plan.lds_bytes;
     e->dflight.st_bytes = st_bytes; e->dflight.da = da;
+    e->dflight.max_blocksize = 0;
+    for (const ChunkDesc& d : plan.descs) e->dflight.max_blocksize = std::max(e->dflight.max_blocksize, (int32_t)d.blocksize);
     return rc;
 }
 
@@ -810,10 +812,10 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     for (int i = 0; i < nchunks; i++) if (st[i] == ERR_CODEC_SUPPORT) { st[i] = 0; unread_chunks.push_back(i); }
     if (!unread_chunks.empty()) {
         DecodeArgs za = da;
-        za.lds_bytes = zstd_kernel_lds_bytes();
+        za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize);
         za.dbg = nullptr; za.done = nullptr; za.skipped = nullptr;
         if (za.lds_bytes > e->lds_per_wg) {
-            for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // (cannot happen on gfx950: 160 KiB per workgroup)
+            for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // blocks too large for one workgroup's LDS (> 72 KiB)
         } else {
             if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
             if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;

@@ -13,10 +13,14 @@
 
 namespace cimg {
 
-enum : int { ZSTD_KERNEL_BLOCK_MAX = 32768 };
+// The launch is sized for the largest block of the batch (rounded up to 64 bytes, at least 32 KiB): `area` bytes for the planes,
+// `area` for the literals, then the tables.  160 KiB of LDS hold blocks of up to 72 KiB that way; the kernel reads `area` back
+// from the launch's LDS size.
+enum : int { ZSTD_KERNEL_AREA_MIN = 32768 };
 CIMG_HD int zstd_work_bytes() { return (int)((sizeof(ZstdWork) + 15) & ~(size_t)15); }
+CIMG_HD int zstd_kernel_area(int max_blocksize) { const int a = (max_blocksize + 63) & ~63; return a < ZSTD_KERNEL_AREA_MIN ? ZSTD_KERNEL_AREA_MIN : a; }
 // the block's planes | the literal buffer (its upper half: a copy of the frame, for streams of half a block or less) | the entropy tables
-CIMG_HD int zstd_kernel_lds_bytes() { return 2 * ZSTD_KERNEL_BLOCK_MAX + zstd_work_bytes() + 64; }
+CIMG_HD int zstd_kernel_lds_bytes(int max_blocksize) { return 2 * zstd_kernel_area(max_blocksize) + zstd_work_bytes() + 64; }
 
 struct DecodeZstdBlock {
     const DecodeArgs& a;
@@ -47,21 +51,22 @@ struct DecodeZstdBlock {
         const int filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE)) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) { fail(chunk, ERR_CODEC_SUPPORT); return; }          // bit rows are never split
-        if (blocksize > ZSTD_KERNEL_BLOCK_MAX || zstd_kernel_lds_bytes() > a.lds_bytes) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        const int area = ((a.lds_bytes - zstd_work_bytes() - 64) >> 1) & ~63;            // zstd_kernel_lds_bytes, read backwards
+        if (area < ZSTD_KERNEL_AREA_MIN || blocksize > area) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         const bool leftover_blk = bsize != blocksize;
         const int ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
         const int neblock = bsize / ns;
         if (cbytes < HEADER_LEN + 4 * d.nblocks) { fail(chunk, ERR_READ_BUFFER); return; }
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { fail(chunk, ERR_DATA); return; }
-        ZstdWork* w = reinterpret_cast<ZstdWork*>(lds + 2 * ZSTD_KERNEL_BLOCK_MAX);
+        ZstdWork* w = reinterpret_cast<ZstdWork*>(lds + 2 * area);
         // streams of at most half a block (the split planes of a 2- or 4-byte type): the literal buffer needs only half of its
         // area and the frame is copied into the other half -- the decoder reads it bit by bit, and an LDS read is a fifth of
         // a global one.  A stream as large as the block keeps the whole literal area; its frame is read where it lies.
-        const bool staged = neblock <= ZSTD_KERNEL_BLOCK_MAX / 2;
-        uint8_t* stage = lds + ZSTD_KERNEL_BLOCK_MAX + ZSTD_KERNEL_BLOCK_MAX / 2;
-        w->lit = lds + ZSTD_KERNEL_BLOCK_MAX;
-        w->lit_cap = staged ? ZSTD_KERNEL_BLOCK_MAX / 2 : ZSTD_KERNEL_BLOCK_MAX;
+        const bool staged = neblock <= area / 2;
+        uint8_t* stage = lds + area + area / 2;
+        w->lit = lds + area;
+        w->lit_cap = staged ? area / 2 : area;
         int pos = bstart;
         for (int s = 0; s < ns; s++) {
             if (cbytes - pos < 4) { fail(chunk, ERR_READ_BUFFER); return; }
@@ -81,7 +86,7 @@ struct DecodeZstdBlock {
             } else if (cs > neblock) {
                 fail(chunk, ERR_DATA); return;
             } else {
-                if (staged) wave_copy_g2l(c + pos, lds, ZSTD_KERNEL_BLOCK_MAX + ZSTD_KERNEL_BLOCK_MAX / 2, cs);   // cs < neblock <= half a block
+                if (staged) wave_copy_g2l(c + pos, lds, area + area / 2, cs);   // cs < neblock <= half the area
                 const int r = zstd_decode_frame(staged ? stage : c + pos, cs, plane, neblock, w);
                 if (r != neblock) { fail(chunk, r < 0 ? r : ERR_DATA); return; }
             }

@@ -147,7 +147,9 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     for (int i = 0; i < nchunks; i++) if (status[i] == ERR_CODEC_SUPPORT) { status[i] = 0; unread = true; }
     if (unread) {
         DecodeArgs za = da;
-        za.lds_bytes = zstd_kernel_lds_bytes();
+        int max_bs = 0;
+        for (const ChunkDesc& d : plan.descs) max_bs = d.blocksize > max_bs ? d.blocksize : max_bs;
+        za.lds_bytes = zstd_kernel_lds_bytes(max_bs);
         za.done = nullptr;
         std::vector<uint8_t> zl((size_t)za.lds_bytes + EMU_LDS_SLACK);
         for (int b = 0; b < plan.total_blocks; b++) {

@@ -105,6 +105,15 @@ def test_chunks_made_with_the_local_libzstd(golden_dir):
                 rc, status, out = E.decompress_batch([chunk], [src.size], [32768])
                 assert rc == 0 and status == [0], (dtype, clevel, filt, status)
                 assert out[0].tobytes() == src.tobytes(), (dtype, clevel, filt)
+    # other block sizes: 64 KiB (the kernel's LDS areas follow the batch's largest block), 4 KiB
+    a = synth.natural_channel(np.uint16, 512, 300)
+    src = np.ascontiguousarray(a).view(np.uint8).ravel()
+    for bs in (65536, 4096):
+        for clevel in (3, 9):
+            chunk = G.frame(z, src, 2, bs, clevel)
+            rc, status, out = E.decompress_batch([chunk], [src.size], [bs])
+            assert rc == 0 and status == [0], (bs, clevel, status)
+            assert out[0].tobytes() == src.tobytes(), (bs, clevel)
 
 
 def test_zstd_chunks_through_the_reference_entry_point_on_the_mock_library(kat):
