@@ -45,6 +45,6 @@ for fam, clevel in (("tiled", 3), ("tiled", 9), ("natural", 3)):
     t0 = time.perf_counter()
     for _ in range(3): eng.decompress_host(lz)
     print("   the same pixels as lz4 chunks through the same host call: %.1f ms" % ((time.perf_counter() - t0) / 3 * 1e3))
-    print("%s clevel %d (%s): %d chunks, ratio %.2f; libzstd compress (python loop, 1 thread) %.2f s; GPU decode incl. PCIe %.1f ms = %.2f GB/s"
+    print("%s clevel %d (%s): %d chunks, ratio %.2f; libzstd compress (python loop, 1 thread) %.2f s; python helper decompress_host (joins and allocates on the host, pageable PCIe) %.1f ms = %.2f GB/s"
           % (fam, clevel, "split planes" if clevel <= 5 else "one stream per block", len(chunks), host.size / csize, t_enc, dt * 1e3, host.size / dt / 1e9))
 os._exit(0)
