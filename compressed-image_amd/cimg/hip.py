@@ -26,6 +26,7 @@ EXPORTS = (
     "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
     "cimg_deinterleave_device", "cimg_compress_batch_host_interleaved_begin",
     "cimg_compress_batch_device_begin", "cimg_compress_batch_device_fetch", "cimg_decompress_batch_device_begin", "cimg_decompress_batch_device_fetch",
+    "cimg_decompress_batch_device_sized", "cimg_decompress_batch_device_begin_sized",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
     "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
     "cimg_engine_debug_stamps", "cimg_engine_read_stamps", "cimg_shared_engine", "cimg_context_cparams",
@@ -86,6 +87,8 @@ def load():
     L.cimg_engine_stream.restype = vp
     L.cimg_compress_batch_device.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_decompress_batch_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_decompress_batch_device_sized.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.cimg_decompress_batch_device_begin_sized.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.cimg_deinterleave_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, C.c_int64]
     L.cimg_compress_batch_host_interleaved_begin.argtypes = [vp, C.POINTER(CParams), C.c_int32, C.c_int64, vp, C.c_int32, vp, vp, vp, vp]
     L.cimg_compress_batch_device_begin.argtypes = [vp, C.POINTER(CParams), C.c_int32, vp, vp, vp, vp, vp, vp]
@@ -224,11 +227,16 @@ class Engine:
                                                       d_comp, _ptr(comp_off), _ptr(destsize), _ptr(cbytes)))
         return cbytes
 
-    def decompress_device(self, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, check=True):
+    def decompress_device(self, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, check=True, comp_size=None):
         raw_off, comp_off, nbytes, blocksize = _i64(raw_off), _i64(comp_off), _i32(nbytes), _i32(blocksize)
         status = np.zeros(nbytes.size, np.int32)
-        rc = load().cimg_decompress_batch_device(self.handle, nbytes.size, d_comp, _ptr(comp_off), _ptr(nbytes), _ptr(blocksize),
-                                                 d_raw, _ptr(raw_off), _ptr(status))
+        if comp_size is not None:       # the caller knows how many bytes each compressed buffer holds
+            comp_size = _i32(comp_size)
+            rc = load().cimg_decompress_batch_device_sized(self.handle, nbytes.size, d_comp, _ptr(comp_off), _ptr(comp_size), _ptr(nbytes),
+                                                           _ptr(blocksize), d_raw, _ptr(raw_off), _ptr(status))
+        else:
+            rc = load().cimg_decompress_batch_device(self.handle, nbytes.size, d_comp, _ptr(comp_off), _ptr(nbytes), _ptr(blocksize),
+                                                     d_raw, _ptr(raw_off), _ptr(status))
         if check:
             self._check(rc)
         return status

@@ -24,6 +24,9 @@ enum : int {
     ERR_FAILURE = -1, ERR_DATA = -3, ERR_READ_BUFFER = -5, ERR_WRITE_BUFFER = -6, ERR_CODEC_SUPPORT = -7,
     ERR_CODEC_PARAM = -8, ERR_VERSION_SUPPORT = -10, ERR_INVALID_HEADER = -11, ERR_INVALID_PARAM = -12,
     ERR_RUN_LENGTH = -17, ERR_MAX_BUFSIZE = -26,
+    // internal, never returned to a caller: cimg_decode_blocks met a zstd chunk (codec format 4), which cimg_decode_zstd reads
+    // (engine.hip: decompress_finish clears exactly these words before that launch)
+    STATUS_ZSTD_PENDING = -1000,
 };
 
 // one per chunk of a batch; built by the host (engine.cpp: plan_chunk)
@@ -31,7 +34,7 @@ struct ChunkDesc {
     int64_t raw_off;      // byte offset of the chunk's pixels in the uncompressed buffer
     int64_t comp_off;     // byte offset of the chunk in the compressed buffer
     int32_t nbytes;       // uncompressed bytes
-    int32_t destsize;     // capacity handed to blosc2_compress_ctx for this chunk (encode only)
+    int32_t destsize;     // encode: capacity handed to blosc2_compress_ctx for this chunk; decode: bytes the compressed buffer holds (INT32_MAX: unknown)
     int32_t blocksize;    // effective block size
     int32_t nblocks;
     int32_t leftover;     // bytes in the last block if it is short, else 0

@@ -743,6 +743,7 @@ struct DecodeBlock {
         const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
         if ((w0 & 0xFF) > 5) { fail(ERR_VERSION_SUPPORT); return; }
         if (nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN) { fail(ERR_INVALID_HEADER); return; }
+        if (cbytes > d.destsize) { fail(ERR_READ_BUFFER); return; }          // the header claims more than the caller's buffer holds: nothing behind the header is read
         if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) { fail(ERR_VERSION_SUPPORT); return; }
         const int special = (int)((b2 >> 28) & 7);
         if (special == SPECIAL_ZERO) { mode = 2; wave_fill_global(out, bsize, 0, wave, 4); return; }
@@ -754,7 +755,7 @@ struct DecodeBlock {
             return;
         }
         const int fmt = flags >> 5;                                  // 0 blosclz, 1 lz4 / lz4hc
-        if (fmt != 0 && fmt != 1) { fail(ERR_CODEC_SUPPORT); return; }
+        if (fmt != 0 && fmt != 1) { fail(fmt == 4 ? STATUS_ZSTD_PENDING : ERR_CODEC_SUPPORT); return; }   // zstd: cimg_decode_zstd's
         // filter pipeline: exactly one of {none, shuffle, bitshuffle}, in the last slot
         filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0) { fail(ERR_CODEC_SUPPORT); return; }

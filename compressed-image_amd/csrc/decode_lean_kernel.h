@@ -51,7 +51,7 @@ struct DecodeLean {
         ts = (int)(w0 >> 24);
         const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z), cbytes = (int)uni(h0.w);
         const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
-        if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || cbytes < HEADER_LEN) return;
+        if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || cbytes < HEADER_LEN || cbytes > d.destsize) return;
         if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) return;
         const int fmt = flags >> 5;                                           // 0 blosclz, 1 lz4 / lz4hc
         if (((b2 >> 28) & 7) != 0 || (flags & (FLAG_MEMCPYED | FLAG_DONT_SPLIT)) || (fmt != 0 && fmt != 1)) return;

@@ -236,12 +236,14 @@ struct cimg_engine {
     // a decode batch between decompress_launch() and decompress_finish()
     struct DecodeFlight {
         bool lean = false, general_now = true, timed = false;
+        bool launched = false;            // decompress_launch got as far as enqueueing kernels: decompress_finish has something to wait for
         int32_t nchunks = 0, total_blocks = 0, lds_bytes = 0, max_blocksize = 0;
         size_t st_bytes = 0;
         DecodeArgs da{};
     } dflight;
     bool dflight_open = false;            // between cimg_decompress_batch_device_begin and _fetch
     int32_t cflight_chunks = -1;          // chunks of the compress batch between _device_begin and _device_fetch (-1: none)
+    bool claunched = false;               // compress_launch got past the planner and the allocations: h_out holds (or will hold) this batch's sizes
 
     int fail(int code, const char* fmt, ...)
     {
@@ -539,6 +541,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
                            void* d_comp, const int64_t* comp_off, const int32_t* destsize)
 {
     (void)hipSetDevice(e->device);
+    e->claunched = false;
     e->begin_batch(0);
     EncodePlan plan;
     int rc = plan_encode_batch(to_host(p), nchunks, raw_off, nbytes, comp_off, destsize, &plan);
@@ -558,6 +561,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         if ((rc = e->hip(hipMemsetAsync(e->queue.p, 0, 64, e->stream), "queue memset"))) return rc;
     }
     e->queue_clean = false;
+    e->claunched = true;                          // from here on kernels may be in flight and h_out is this batch's
 
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
@@ -641,6 +645,7 @@ static int compress_finish(cimg_engine* e, int32_t nchunks, int32_t* cbytes)
 {
     int rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
+    if (!e->claunched) return 0;                  // the batch was rejected before anything ran: there are no sizes to read
     const ChunkLayout* lay = (const ChunkLayout*)e->h_out.p;
     for (int i = 0; i < nchunks; i++) cbytes[i] = lay[i].cbytes;
     return 0;
@@ -685,12 +690,15 @@ int cimg_compress_batch_device_fetch(cimg_engine* e, int32_t nchunks, int32_t* c
 // the kernels of one decode batch, enqueued on the engine's stream; decompress_finish() waits, launches the general
 // kernel late if the lean one left blocks behind, and collects the status words
 static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
-                             const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off)
+                             const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
+                             const int32_t* comp_size = nullptr)
 {
     (void)hipSetDevice(e->device);
+    e->dflight.launched = false;                  // a rejected batch must not be finished on the previous batch's state
+    e->dflight.nchunks = 0;
     e->begin_batch(1);
     DecodePlan plan;
-    int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan);
+    int rc = plan_decode_batch(nchunks, comp_off, nbytes, blocksize, raw_off, &plan, comp_size);
     if (rc < 0) return e->fail(rc, "decompress batch rejected by the planner (code %d)", rc);
     if (plan.lds_lean > 0) plan.lds_lean += e->lean_lds_pad;
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
@@ -773,12 +781,14 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     e->dflight.st_bytes = st_bytes; e->dflight.da = da;
     e->dflight.max_blocksize = 0;
     for (const ChunkDesc& d : plan.descs) e->dflight.max_blocksize = std::max(e->dflight.max_blocksize, (int32_t)d.blocksize);
+    e->dflight.launched = true;
     return rc;
 }
 
 static int decompress_finish(cimg_engine* e, int32_t* status)
 {
     const cimg_engine::DecodeFlight& f = e->dflight;
+    if (!f.launched) return cimg_engine_synchronize(e);          // nothing of this batch was enqueued (planner / allocation failure)
     const bool lean = f.lean, general_now = f.general_now, timed = f.timed;
     const int32_t nchunks = f.nchunks;
     const DecodeArgs da = f.da;
@@ -805,11 +815,11 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
         }
     }
     int32_t* st = (int32_t*)e->h_dec.p;
-    // Chunks in a codec format the kernels above do not read came back with ERR_CODEC_SUPPORT.  zstd (format 4) has a decoder
-    // of its own -- slow, one wave per block, only ever launched here: their status is cleared, cimg_decode_zstd goes over the
-    // batch (it leaves every other chunk alone and reports formats nobody reads again), and the words are read once more.
+    // zstd chunks (codec format 4) came back with the internal word STATUS_ZSTD_PENDING: they have a decoder of their own -- one
+    // wave per block, only ever launched here.  Exactly those words are cleared (a chunk of this engine's codecs with a filter
+    // pipeline nobody reads keeps its ERR_CODEC_SUPPORT), cimg_decode_zstd goes over the batch, and the words are read once more.
     std::vector<int> unread_chunks;
-    for (int i = 0; i < nchunks; i++) if (st[i] == ERR_CODEC_SUPPORT) { st[i] = 0; unread_chunks.push_back(i); }
+    for (int i = 0; i < nchunks; i++) if (st[i] == STATUS_ZSTD_PENDING) { st[i] = 0; unread_chunks.push_back(i); }
     if (!unread_chunks.empty()) {
         DecodeArgs za = da;
         za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize);
@@ -836,24 +846,39 @@ int cimg_decompress_batch_device(cimg_engine* e, int32_t nchunks, const void* d_
                                  const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
                                  int32_t* status)
 {
+    return cimg_decompress_batch_device_sized(e, nchunks, d_comp, comp_off, nullptr, nbytes, blocksize, d_raw, raw_off, status);
+}
+
+int cimg_decompress_batch_device_sized(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                       const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
+                                       int32_t* status)
+{
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     if (nchunks <= 0) return 0;
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     e->dflight_open = false;
-    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off);
-    return rc ? rc : decompress_finish(e, status);
+    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, comp_size);
+    if (rc) { if (e->dflight.launched) (void)cimg_engine_synchronize(e); return rc; }
+    return decompress_finish(e, status);
 }
 
 int cimg_decompress_batch_device_begin(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
                                        const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off)
+{
+    return cimg_decompress_batch_device_begin_sized(e, nchunks, d_comp, comp_off, nullptr, nbytes, blocksize, d_raw, raw_off);
+}
+
+int cimg_decompress_batch_device_begin_sized(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                             const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off)
 {
     std::lock_guard<std::recursive_mutex> lock_(e->mu);
     e->dflight_open = false;
     e->dflight.nchunks = 0;
     if (nchunks <= 0) { e->dflight_open = true; return 0; }
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
-    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off);
+    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, comp_size);
     if (!rc) e->dflight_open = true;
+    else if (e->dflight.launched) (void)cimg_engine_synchronize(e);
     return rc;
 }
 
@@ -1113,7 +1138,7 @@ int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void
         if (comp_size && comp_size[i] < HEADER_LEN) return e->fail(ERR_READ_BUFFER, "chunk %d: %d bytes cannot hold a header", i, comp_size[i]);
         memcpy(&n, c + OFF_NBYTES, 4); memcpy(&b, c + OFF_BLOCKSIZE, 4); memcpy(&cbv, c + OFF_CBYTES, 4);
         if (c[0] > 5) return e->fail(ERR_VERSION_SUPPORT, "chunk %d: format version %d", i, c[0]);
-        if (cbv < HEADER_LEN || b <= 0 || (n > 0 && b > n) || c[OFF_TYPESIZE] == 0) return e->fail(ERR_INVALID_HEADER, "chunk %d: invalid header", i);
+        if (n < 0 || cbv < HEADER_LEN || b <= 0 || (n > 0 && b > n) || c[OFF_TYPESIZE] == 0) return e->fail(ERR_INVALID_HEADER, "chunk %d: invalid header", i);
         if (comp_size && cbv > comp_size[i]) return e->fail(ERR_READ_BUFFER, "chunk %d: header says %d compressed bytes, the buffer holds %d", i, cbv, comp_size[i]);
         if (n > raw_capacity[i]) return e->fail(ERR_WRITE_BUFFER, "chunk %d: needs %d bytes, buffer has %d", i, n, raw_capacity[i]);
         nb[(size_t)i] = n; bs[(size_t)i] = b; cb[(size_t)i] = cbv;
@@ -1137,10 +1162,11 @@ int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void
     if (ng == 1) {
         if ((rc = copy_in(e, e->stream, sc, d_comp_off.data(), hc, comp_off, cb.data(), 0, nchunks, "chunk H2D"))) return rc;
         rc = decompress_launch(e, nchunks, sc, d_comp_off.data(), nb.data(), bs.data(), sr, d_raw_off.data());
+        if (!e->dflight.launched) { (void)cimg_engine_synchronize(e); return rc; }     // rejected before anything was enqueued
         int drc = rc;
-        if (!rc || rc != ERR_FAILURE) { const int frc = decompress_finish(e, st.data()); if (!drc) drc = frc; }
+        { const int frc = decompress_finish(e, st.data()); if (!drc) drc = frc; }
         if (status) memcpy(status, st.data(), sizeof(int32_t) * (size_t)nchunks);
-        if (drc == ERR_FAILURE) return drc;
+        if (rc || drc == ERR_FAILURE) return drc;
         const std::string chunk_error1 = e->err;
         for (int i = 0; i < nchunks; i++) deliver[(size_t)i] = (nb[(size_t)i] > 0 && st[(size_t)i] == 0) ? nb[(size_t)i] : 0;
         if ((rc = copy_out(e, e->stream, hr, raw_off, sr, d_raw_off.data(), deliver.data(), 0, nchunks, "pixels D2H"))) return rc;
@@ -1162,8 +1188,9 @@ int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void
             if (!crc) crc = e->hip(hipEventRecord(e->ev_h2d[(g + 1) & 1], e->s_h2d), "event record");
         }
         int drc = rc;
-        if (!rc || rc != ERR_FAILURE) { const int frc = decompress_finish(e, st.data() + a); if (!drc) drc = frc; }
-        if (drc == ERR_FAILURE || crc) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamSynchronize(e->s_d2h); return crc ? crc : drc; }
+        if (e->dflight.launched) { const int frc = decompress_finish(e, st.data() + a); if (!drc) drc = frc; }
+        else (void)cimg_engine_synchronize(e);
+        if (rc || drc == ERR_FAILURE || crc) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamSynchronize(e->s_d2h); return crc ? crc : drc; }
         if (drc && !first_bad) { first_bad = drc; chunk_error = e->err; }
         // chunks that decoded cleanly are still delivered when a neighbour in the batch is damaged
         for (int i = a; i < b; i++) deliver[(size_t)i] = (nb[(size_t)i] > 0 && st[(size_t)i] == 0) ? nb[(size_t)i] : 0;

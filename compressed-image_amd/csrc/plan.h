@@ -76,13 +76,13 @@ inline int plan_chunk(const HostCParams& p, int32_t nbytes, int32_t destsize, Ch
     if (d->leftover) d->nblocks++;
     d->memcpyed = (p.clevel == 0 || nbytes < MIN_BUFFERSIZE) ? 1 : 0;
     d->flags = FLAG_SHUFFLE | FLAG_BITSHUFFLE;
-    if (d->memcpyed) {
-        d->flags |= FLAG_MEMCPYED;
-    } else {
-        d->split = wants_split(p, ts, bs) ? 1 : 0;
-        if (!d->split) d->flags |= FLAG_DONT_SPLIT;
-        d->flags |= compformat_of(p.compcode) << 5;
-    }
+    // one rule for the header's flags byte: the dont-split bit and the codec format are set whether or not the chunk is
+    // memcpyed up front (oracle/chunk.c: orc_chunk_geometry says where that comes from)
+    const bool split = wants_split(p, ts, bs);
+    if (!split) d->flags |= FLAG_DONT_SPLIT;
+    d->flags |= compformat_of(p.compcode) << 5;
+    if (d->memcpyed) d->flags |= FLAG_MEMCPYED;
+    else d->split = split ? 1 : 0;
     if (d->split) d->nstreams = d->leftover ? (d->nblocks - 1) * ts + 1 : d->nblocks * ts;
     else d->nstreams = d->nblocks;
     return 0;
@@ -178,8 +178,10 @@ inline int decode_lds_bound(int blocksize)
 }
 
 // nbytes / blocksize come from the chunk headers (the host reads them; blosc2_cbuffer_sizes)
+// comp_size (optional): bytes each compressed buffer really holds; it travels in ChunkDesc::destsize (INT32_MAX = unknown) and
+// the kernels refuse a header that claims more before they read anything behind the header
 inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t* nbytes, const int32_t* blocksize,
-                             const int64_t* raw_off, DecodePlan* plan)
+                             const int64_t* raw_off, DecodePlan* plan, const int32_t* comp_size = nullptr)
 {
     plan->descs.resize((size_t)nchunks);
     int32_t blk = 0, lds = 0, max_bs = 0;
@@ -190,6 +192,8 @@ inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t
         d.raw_off = raw_off[i];
         d.comp_off = comp_off[i];
         d.nbytes = nbytes[i];
+        d.destsize = comp_size ? comp_size[i] : 0x7fffffff;
+        if (d.destsize < HEADER_LEN) return ERR_READ_BUFFER;
         d.blocksize = blocksize[i];
         d.nblocks = nbytes[i] / blocksize[i];
         d.leftover = nbytes[i] % blocksize[i];

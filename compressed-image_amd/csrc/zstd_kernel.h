@@ -2,8 +2,8 @@
 // chunks the reference wrote with enums::codec::zstd (enums.h:18-24) stay readable; nothing here is tuned.
 //
 // The engine launches this kernel only behind a batch in which cimg_decode_blocks reported ERR_CODEC_SUPPORT for some chunk
-// (engine.hip: decompress_finish).  A block of any other chunk is left alone; a chunk with a codec format that no kernel
-// reads (zlib, user codecs) gets ERR_CODEC_SUPPORT again.  LDS: the block's streams decoded back to back, the literal buffer
+// (engine.hip: decompress_finish clears STATUS_ZSTD_PENDING words only).  A block of any other chunk is left alone, whatever
+// its status says.  LDS: the block's streams decoded back to back, the literal buffer
 // of the frame being decoded -- which for streams of half a block or less shares its area with a copy of the frame --, the
 // entropy tables (zstd_decode.h: ZstdWork): 76 KiB, two blocks per CU.  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
 // filter stage at the end (the general kernel's) and the byte movers are the lane-parallel parts.
@@ -42,12 +42,11 @@ struct DecodeZstdBlock {
         const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z), cbytes = (int)uni(h0.w);
         const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
         // whatever cimg_decode_blocks already settled -- damaged headers, special and memcpyed chunks, its own codecs -- is not ours
-        if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN) return;
+        if ((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN || cbytes > d.destsize) return;
         if ((flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) != (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) return;
         if (((b2 >> 28) & 7) != 0 || (flags & FLAG_MEMCPYED)) return;
         const int fmt = flags >> 5;
-        if (fmt == 0 || fmt == 1) return;
-        if (fmt != 4) { fail(chunk, ERR_CODEC_SUPPORT); return; }
+        if (fmt != 4) return;                                           // its own codecs, and formats nobody reads (reported already)
         const int filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE)) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) { fail(chunk, ERR_CODEC_SUPPORT); return; }          // bit rows are never split

@@ -13,11 +13,13 @@
 // (1) recompresses it and stores its chunks, then (2) decodes window k + 1 into a second page-locked buffer -- both
 // while the caller's loop body works on window k.  The next window switch only waits for that task.  The engine calls
 // are the same batched ones (one encode, one decode per window); they are serialised by the engine's own lock, so
-// several iterators (ranges::zip over three channels) interleave their windows on one device.  Consequences, beyond
-// the window rule above: chunks of window k + 1 are read up to one window early, so writing them through the channel
-// (set_chunk) while an iterator is about to enter them is not seen by that iterator; an exception of the helper
-// task (a codec error) surfaces at the next window switch or is swallowed by the destructor, like the reference's
-// destructor does (iterator.h:72-93).
+// several iterators (ranges::zip over three channels) interleave their windows on one device.  The helper task never
+// WRITES the channel's chunk table: it hands the recompressed chunks back and the iterator's own thread stores them at
+// the next window switch (wait()), so reading the channel's sizes inside the loop body does not race with it.
+// Consequences, beyond the window rule above: chunks of window k + 1 are read up to one window early, so writing them
+// through the channel (set_chunk) while an iterator is about to enter them is undefined (the reference is strictly serial
+// here; CIMG_ITERATOR_SERIAL=1 gives its order); an exception of the helper task (a codec error) surfaces at the next
+// window switch or is swallowed by the destructor, like the reference's destructor does (iterator.h:72-93).
 #pragma once
 #include <cstddef>
 #include <cstdlib>
@@ -134,9 +136,15 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			bool overlaps(size_t lo, size_t hi) const noexcept { return first != npos && lo < first + elems.size() && first < hi; }
 			void drop() { first = npos; offset.clear(); elems.clear(); visited.clear(); buffer.reset(); }
 		};
+		// the visited chunks of a window, recompressed with ONE engine call, and where they belong
+		struct recoded
+		{
+			std::vector<blosc2::byte_buffer> chunks;
+			std::vector<size_t> where;
+		};
 		window m_Cur;                                  // the window the caller is working on
 		std::shared_ptr<window> m_Ahead;               // filled by the helper task: the window after m_Cur
-		std::future<void> m_Task;                      // write-back of the previous window, then the read-ahead
+		std::future<recoded> m_Task;                   // the previous window recompressed (stored by wait()), then the read-ahead
 
 		size_t num_chunks() const { return m_Schunk ? std::visit([](auto& s) { return s.num_chunks(); }, *m_Schunk) : 0; }
 
@@ -162,24 +170,34 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			w.first = first;
 		}
 
-		// write the visited chunks of a window back, compressed with ONE engine call
-		static void store_window(blosc2::schunk_var<T>& schunk, blosc2::context_raw_ptr cctx, window& w)
+		static recoded recode_window(size_t nominal_chunk_bytes, blosc2::context_raw_ptr cctx, window& w)
 		{
-			if (w.first == npos) return;
+			recoded r;
+			if (w.first == npos) return r;
 			std::vector<blosc2::batch::piece> pieces;
-			std::vector<size_t> where;
 			for (size_t k = 0; k < w.visited.size(); ++k)
 				if (w.visited[k])
 				{
 					pieces.push_back({ w.buffer.get() + w.offset[k] * sizeof(T), w.elems[k] * sizeof(T) });
-					where.push_back(w.first + k);
+					r.where.push_back(w.first + k);
 				}
 			w.first = npos;
-			if (pieces.empty()) return;
+			if (pieces.empty()) return r;
+			r.chunks = blosc2::batch::compress(cctx, pieces, nominal_chunk_bytes);
+			return r;
+		}
+		// the only place an iterator WRITES the chunk table -- always on the thread that owns the iterator
+		static void apply(blosc2::schunk_var<T>& schunk, recoded&& r)
+		{
+			for (size_t i = 0; i < r.chunks.size(); ++i)
+				std::visit([&](auto& s) { s.set_chunk(std::move(r.chunks[i]), r.where[i]); }, schunk);
+			r.chunks.clear(); r.where.clear();
+		}
+		// write the visited chunks of a window back (caller's thread)
+		static void store_window(blosc2::schunk_var<T>& schunk, blosc2::context_raw_ptr cctx, window& w)
+		{
 			const size_t nominal = std::visit([](auto& s) { return s.chunk_bytes(); }, schunk);
-			auto chunks = blosc2::batch::compress(cctx, pieces, nominal);
-			for (size_t i = 0; i < chunks.size(); ++i)
-				std::visit([&](auto& s) { s.set_chunk(std::move(chunks[i]), where[i]); }, schunk);
+			apply(schunk, recode_window(nominal, cctx, w));
 		}
 
 		static bool serial()
@@ -188,10 +206,10 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			return on;
 		}
 
-		// wait for the helper task; its exception (if any) is rethrown here
+		// wait for the helper task and put the chunks it recompressed into the table; its exception (if any) is rethrown here
 		void wait()
 		{
-			if (m_Task.valid()) m_Task.get();
+			if (m_Task.valid()) apply(*m_Schunk, m_Task.get());
 		}
 
 		// The caller moves on to the window that starts at (or holds) `index`: take the read-ahead if it is the right one,
@@ -220,12 +238,18 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 			if (left.first == npos && !ahead) return;
 			auto target = ahead ? std::make_shared<window>() : std::shared_ptr<window>();
 			m_Ahead = target;
+			// The task only READS the chunk table (the compressed bytes of window k + 1, which this iterator does not write while
+			// the task runs) and never writes it: what it recompressed comes back through the future and is stored by wait() on
+			// this thread.  The caller's own reads during the loop body (num_chunks, chunk_bytes, ...) are therefore reads
+			// beside reads.
+			const size_t nominal = chunk_bytes();
 			m_Task = std::async(std::launch::async,
-				[schunk = m_Schunk, cctx = m_Cctx, left = std::move(left), target, next]() mutable
+				[schunk = m_Schunk, cctx = m_Cctx, left = std::move(left), target, next, nominal]() mutable
 				{
-					store_window(*schunk, cctx, left);
+					recoded r = recode_window(nominal, cctx, left);
 					left.drop();
 					if (target) load_window(*schunk, *target, next);
+					return r;
 				});
 		}
 

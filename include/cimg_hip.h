@@ -90,6 +90,18 @@ int cimg_decompress_batch_device_begin(cimg_engine* e, int32_t nchunks,
                                        const int32_t* nbytes, const int32_t* blocksize,
                                        void* d_raw, const int64_t* raw_off);
 int cimg_decompress_batch_device_fetch(cimg_engine* e, int32_t* status);
+/* Device-resident decode for callers that know how many bytes each compressed buffer really holds (comp_size[i]; at least 32).
+ * The reference passes INT32_MAX as srcsize (blosc2/wrapper.h:249), so the callee is the one that must be careful: a header
+ * whose cbytes exceeds comp_size[i] gets BLOSC2_ERROR_READ_BUFFER for that chunk and the kernels read nothing of it behind
+ * the 32-byte header (the unsized calls above trust the header's cbytes).  Otherwise as the unsized calls. */
+int cimg_decompress_batch_device_sized(cimg_engine* e, int32_t nchunks,
+                                       const void* d_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                       const int32_t* nbytes, const int32_t* blocksize,
+                                       void* d_raw, const int64_t* raw_off, int32_t* status);
+int cimg_decompress_batch_device_begin_sized(cimg_engine* e, int32_t nchunks,
+                                             const void* d_comp, const int64_t* comp_off, const int32_t* comp_size,
+                                             const int32_t* nbytes, const int32_t* blocksize,
+                                             void* d_raw, const int64_t* raw_off);
 
 /* ---- interleaved pixels -> planes (reference: image_algo::deinterleave, compressed/image_algo.h:84-111, the step between
  * reading scanlines and compressing them in the read path, image.h:1880) -------------------------------------------

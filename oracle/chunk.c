@@ -98,12 +98,17 @@ int orc_chunk_geometry(const orc_cparams* p, int32_t nbytes, orc_geometry* g)
     if (g->leftover) g->nblocks++;
     g->memcpyed = (p->clevel == 0) || (nbytes < MIN_BUFFERSIZE);
     g->flags = FLAG_SHUFFLE | FLAG_BITSHUFFLE;      /* both set == "extended header" */
-    if (g->memcpyed) {
-        g->flags |= FLAG_MEMCPYED;
-    } else {
-        g->split = wants_split(p, ts, bs);
-        if (!g->split) g->flags |= FLAG_DONT_SPLIT;
+    /* ONE rule for byte 2 of the header (round 3): upstream's write_compression_header ORs the dont-split bit
+     * (bit 4, from split_block) and the codec format (bits 5-7) into header_flags in one place, whether or not the chunk
+     * was marked memcpyed up front (clevel 0, nbytes < 32) -- so an up-front memcpyed chunk carries them exactly like a
+     * chunk that fell back to memcpyed after compression did not fit (finish_memcpyed keeps g->flags).  [UPSTREAM-RECALL]:
+     * to be re-checked by tests/test_conformance_cblosc2.py the day a libblosc2 is present. */
+    {
+        const int split = wants_split(p, ts, bs);
+        if (!split) g->flags |= FLAG_DONT_SPLIT;
         g->flags |= compformat_of(p->compcode) << 5;
+        if (g->memcpyed) g->flags |= FLAG_MEMCPYED;
+        else g->split = split;
     }
     if (g->split)
         g->nstreams_total = g->leftover ? (g->nblocks - 1) * ts + 1 : g->nblocks * ts;

@@ -144,7 +144,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     }
     // as the engine does (decompress_finish): chunks nobody read yet go to the zstd kernel
     bool unread = false;
-    for (int i = 0; i < nchunks; i++) if (status[i] == ERR_CODEC_SUPPORT) { status[i] = 0; unread = true; }
+    for (int i = 0; i < nchunks; i++) if (status[i] == STATUS_ZSTD_PENDING) { status[i] = 0; unread = true; }
     if (unread) {
         DecodeArgs za = da;
         int max_bs = 0;

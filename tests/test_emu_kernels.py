@@ -283,3 +283,23 @@ def test_encode_work_item_shapes_give_the_same_bytes():
                     assert rc == 0 and chunks == want, (dtype, code, mode)
     finally:
         E.set_block_items(1)
+
+
+def test_own_codec_with_an_unreadable_filter_is_an_error_not_a_zstd_retry():
+    """An lz4 chunk whose header names a filter the kernels do not implement (delta, trunc_prec, a second filter) is
+    BLOSC2_ERROR_CODEC_SUPPORT (-7).  The engine retries chunks of codec format 4 (zstd) with cimg_decode_zstd; a round-2 build
+    cleared EVERY -7 before that launch and such chunks ended with status 0 and no pixels."""
+    a = synth.tiled_channel(np.float16, 512, 64)
+    raw = a.view(np.uint8).ravel()
+    rc, cb, chunks = E.compress_batch(E.cparams(2), raw, [raw.size], [raw.size + 32])
+    good = chunks[0]
+    for slot, code in ((20, 3), (21, 3), (21, 4), (19, 1)):
+        bad = bytearray(good)
+        bad[slot] = code
+        rc, status, outs = E.decompress_batch([bytes(bad), good], [raw.size] * 2, [32768] * 2)
+        assert status == [-7, 0], (slot, code, status)
+        assert outs[1].tobytes() == raw.tobytes()
+    bad = bytearray(good)
+    bad[2] = (bad[2] & 0x1F) | (3 << 5)                                # codec format 3 (zlib): nobody reads it
+    rc, status, outs = E.decompress_batch([bytes(bad)], [raw.size], [32768])
+    assert status == [-7]
