@@ -12,7 +12,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("CIMG_LIB") or os.path.join(_PKG, "libcimg_hip.so")   # CIMG_LIB: diagnostic builds
 
-K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE = 0, 1, 2, 3
+K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE, K_DEINTERLEAVE, K_DECODE_ZSTD, K_ENCODE_ZSTD = 0, 1, 2, 3, 4, 5, 6
 KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")   # the decode entry times cimg_decode_lean + cimg_decode_blocks together
 BLOSCLZ, LZ4, LZ4HC, ZLIB, ZSTD = 0, 1, 2, 4, 5
 NOFILTER, SHUFFLE, BITSHUFFLE = 0, 1, 2

@@ -371,6 +371,8 @@ const char* cimg_kernel_name(int k)
     case CIMG_K_EMIT: return "cimg_emit_blocks";
     case CIMG_K_DECODE: return "cimg_decode_blocks";
     case CIMG_K_DEINTERLEAVE: return "cimg_deinterleave";
+    case CIMG_K_DECODE_ZSTD: return "cimg_decode_zstd";
+    case CIMG_K_ENCODE_ZSTD: return "cimg_encode_zstd";
     default: return "?";
     }
 }
@@ -828,7 +830,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
             for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // blocks too large for one workgroup's LDS (> 72 KiB)
         } else {
             if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
-            if ((rc = e->launch(CIMG_K_DECODE, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;
+            if ((rc = e->launch(CIMG_K_DECODE_ZSTD, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;
             if ((rc = cimg_engine_synchronize(e))) return rc;
             e->zstd_batches++;
         }

@@ -163,7 +163,12 @@ static int codec_compress(const orc_cparams* p, const uint8_t* s, int n, uint8_t
 {
     if (p->compcode == ORC_LZ4) return orc_lz4_compress_fast(s, n, d, maxout, 10 - p->clevel, need);
     if (p->compcode == ORC_BLOSCLZ) return orc_blosclz_compress(p->clevel, s, n, d, maxout, need);
-    return ORC_ERR_CODEC_SUPPORT;          /* lz4hc / zstd encoders are not restated (their chunks still decode) */
+    if (p->compcode == ORC_ZSTD) {          /* the box's libzstd (zstd_dl.c): a frame fits iff the budget holds its bytes */
+        const int r = orc_zstd_compress_stream(p->clevel, s, n, d, maxout);
+        if (need && r > 0) *need = r;
+        return r;
+    }
+    return ORC_ERR_CODEC_SUPPORT;          /* the lz4hc encoder is not restated (its chunks still decode) */
 }
 
 /* one block, written at dst (= chunk + ntbytes).  Returns block bytes, 0 = does not fit, <0 error. */
@@ -280,7 +285,7 @@ int orc_blosc2_compress_2phase(const orc_cparams* p, const void* src_, int32_t n
     const int ts = p->typesize > MAX_TYPESIZE ? 1 : p->typesize;
     write_header(p, &g, nbytes, dst);
     if (g.memcpyed) return finish_memcpyed(&g, src, nbytes, dst, destsize);
-    if (p->compcode != ORC_LZ4 && p->compcode != ORC_BLOSCLZ) return ORC_ERR_CODEC_SUPPORT;
+    if (p->compcode != ORC_LZ4 && p->compcode != ORC_BLOSCLZ && p->compcode != ORC_ZSTD) return ORC_ERR_CODEC_SUPPORT;
 
     const int maxstreams = g.split ? ts : 1;
     const size_t slot = (size_t)g.blocksize + 16;
@@ -368,7 +373,63 @@ int orc_blosc2_cbuffer_sizes(const void* cbuffer, int32_t* nbytes, int32_t* cbyt
     return 0;
 }
 
+/* one block of a regular chunk: streams -> tmpa, backward filter pipeline -> dst + j * blocksize.  0 or an error code. */
+static int decode_one_block(const uint8_t* src, int32_t cbytes, int32_t blocksize, int nblocks, int leftover, int ts, int dont_split,
+                            int compformat, int j, uint8_t* dst, uint8_t* tmpa, uint8_t* tmpb)
+{
+    const uint8_t* filters = src + OFF_FILTERS;
+    int bsize = blocksize, lo = 0;
+    if (j == nblocks - 1 && leftover) { bsize = leftover; lo = 1; }
+    const int32_t bstart = get32(src + ORC_HEADER_LEN + 4 * j);
+    if (bstart < ORC_HEADER_LEN + 4 * nblocks || bstart > cbytes) return ORC_ERR_DATA;
+    const uint8_t* ip = src + bstart;
+    int32_t left = cbytes - bstart;
+    const int nstreams = (!dont_split && !lo) ? ts : 1;
+    const int neblock = bsize / nstreams;
+    for (int s = 0; s < nstreams; s++) {
+        uint8_t* out = tmpa + (size_t)s * neblock;
+        if (left < 4) return ORC_ERR_READ_BUFFER;
+        int32_t cs = get32(ip); ip += 4; left -= 4;
+        if (cs == 0) { memset(out, 0, (size_t)neblock); continue; }
+        if (cs < 0) {
+            if (left < 1) return ORC_ERR_READ_BUFFER;
+            const int token = *ip++; left--;
+            if (!(token & 1) || cs < -255) return ORC_ERR_RUN_LENGTH;
+            memset(out, -cs, (size_t)neblock);
+            continue;
+        }
+        if (cs > left) return ORC_ERR_READ_BUFFER;
+        if (cs == neblock) memcpy(out, ip, (size_t)neblock);
+        else if ((compformat == 1 ? orc_lz4_decompress_safe(ip, cs, out, neblock)
+                  : compformat == 4 ? orc_zstd_decompress_stream(ip, cs, out, neblock)
+                                    : orc_blosclz_decompress(ip, cs, out, neblock)) != neblock) return ORC_ERR_DATA;
+        ip += cs; left -= cs;
+    }
+    /* backward filter pipeline */
+    uint8_t* cur = tmpa; uint8_t* other = tmpb;
+    int last = -1;
+    for (int i = 0; i < ORC_MAX_FILTERS; i++)
+        if (filters[i] == ORC_SHUFFLE || filters[i] == ORC_BITSHUFFLE) last = i;
+    uint8_t* final_out = dst + (size_t)j * blocksize;
+    if (last < 0) memcpy(final_out, cur, (size_t)bsize);
+    for (int i = ORC_MAX_FILTERS - 1; i >= 0; i--) {
+        if (filters[i] != ORC_SHUFFLE && filters[i] != ORC_BITSHUFFLE) continue;
+        int first = 1;
+        for (int k = 0; k < i; k++) if (filters[k] == ORC_SHUFFLE || filters[k] == ORC_BITSHUFFLE) first = 0;
+        uint8_t* out = first ? final_out : other;
+        if (filters[i] == ORC_SHUFFLE) orc_unshuffle(ts, bsize, cur, out);
+        else orc_bitunshuffle(ts, bsize, cur, out);
+        other = cur; cur = out;
+    }
+    return 0;
+}
+
 int orc_blosc2_decompress(const void* src_, int32_t srcsize, void* dst_, int32_t destsize)
+{
+    return orc_blosc2_decompress_mt(src_, srcsize, dst_, destsize, 1);
+}
+
+int orc_blosc2_decompress_mt(const void* src_, int32_t srcsize, void* dst_, int32_t destsize, int nthreads)
 {
     const uint8_t* src = (const uint8_t*)src_;
     uint8_t* dst = (uint8_t*)dst_;
@@ -403,64 +464,41 @@ int orc_blosc2_decompress(const void* src_, int32_t srcsize, void* dst_, int32_t
         return nbytes;
     }
     const int compformat = flags >> 5;
-    if (compformat != 0 && compformat != 1) return ORC_ERR_CODEC_SUPPORT;   /* blosclz; lz4 and lz4hc share format 1 */
+    if (compformat != 0 && compformat != 1 && compformat != 4) return ORC_ERR_CODEC_SUPPORT;   /* blosclz; lz4 and lz4hc share format 1; zstd = 4 */
+    if (compformat == 4 && !orc_zstd_available()) return ORC_ERR_CODEC_SUPPORT;
     const int dont_split = (flags & FLAG_DONT_SPLIT) != 0;
     int nblocks = nbytes / blocksize;
     const int leftover = nbytes % blocksize;
     if (leftover) nblocks++;
     if (cbytes < ORC_HEADER_LEN + 4 * nblocks) return ORC_ERR_READ_BUFFER;
-    const uint8_t* filters = src + OFF_FILTERS;
+    rc = nbytes;
+    if (nthreads > 1 && nblocks > 1) {
+        /* blocks are independent (bstarts[]): the all-cores CPU baseline of bench.py spreads them over threads, like c-blosc2's
+         * parallel_blosc does for nthreads > 1 (the reference itself decodes with ONE thread, blosc2/wrapper.h:406) */
+        int err = 0;
+#pragma omp parallel num_threads(nthreads)
+        {
+            uint8_t* ta = (uint8_t*)malloc((size_t)blocksize * 2 + 16);
+#pragma omp for schedule(dynamic, 4)
+            for (int j = 0; j < nblocks; j++) {
+                const int r = ta ? decode_one_block(src, cbytes, blocksize, nblocks, leftover, ts, dont_split, compformat, j, dst, ta, ta + blocksize + 8)
+                                 : ORC_ERR_FAILURE;
+                if (r < 0) {
+#pragma omp critical
+                    { if (!err) err = r; }
+                }
+            }
+            free(ta);
+        }
+        return err ? err : rc;
+    }
     uint8_t* tmpa = (uint8_t*)malloc((size_t)blocksize * 2 + 16);
     if (!tmpa) return ORC_ERR_FAILURE;
     uint8_t* tmpb = tmpa + blocksize + 8;
-    rc = nbytes;
     for (int j = 0; j < nblocks; j++) {
-        int bsize = blocksize, lo = 0;
-        if (j == nblocks - 1 && leftover) { bsize = leftover; lo = 1; }
-        const int32_t bstart = get32(src + ORC_HEADER_LEN + 4 * j);
-        if (bstart < ORC_HEADER_LEN + 4 * nblocks || bstart > cbytes) { rc = ORC_ERR_DATA; break; }
-        const uint8_t* ip = src + bstart;
-        int32_t left = cbytes - bstart;
-        const int nstreams = (!dont_split && !lo) ? ts : 1;
-        const int neblock = bsize / nstreams;
-        for (int s = 0; s < nstreams; s++) {
-            uint8_t* out = tmpa + (size_t)s * neblock;
-            if (left < 4) { rc = ORC_ERR_READ_BUFFER; goto done; }
-            int32_t cs = get32(ip); ip += 4; left -= 4;
-            if (cs == 0) { memset(out, 0, (size_t)neblock); continue; }
-            if (cs < 0) {
-                if (left < 1) { rc = ORC_ERR_READ_BUFFER; goto done; }
-                const int token = *ip++; left--;
-                if (!(token & 1) || cs < -255) { rc = ORC_ERR_RUN_LENGTH; goto done; }
-                memset(out, -cs, (size_t)neblock);
-                continue;
-            }
-            if (cs > left) { rc = ORC_ERR_READ_BUFFER; goto done; }
-            if (cs == neblock) memcpy(out, ip, (size_t)neblock);
-            else if ((compformat == 1 ? orc_lz4_decompress_safe(ip, cs, out, neblock)
-                                      : orc_blosclz_decompress(ip, cs, out, neblock)) != neblock) { rc = ORC_ERR_DATA; goto done; }
-            ip += cs; left -= cs;
-        }
-        /* backward filter pipeline */
-        {
-            uint8_t* cur = tmpa; uint8_t* other = tmpb;
-            int last = -1;
-            for (int i = 0; i < ORC_MAX_FILTERS; i++)
-                if (filters[i] == ORC_SHUFFLE || filters[i] == ORC_BITSHUFFLE) last = i;
-            uint8_t* final_out = dst + (size_t)j * blocksize;
-            if (last < 0) memcpy(final_out, cur, (size_t)bsize);
-            for (int i = ORC_MAX_FILTERS - 1; i >= 0; i--) {
-                if (filters[i] != ORC_SHUFFLE && filters[i] != ORC_BITSHUFFLE) continue;
-                int first = 1;
-                for (int k = 0; k < i; k++) if (filters[k] == ORC_SHUFFLE || filters[k] == ORC_BITSHUFFLE) first = 0;
-                uint8_t* out = first ? final_out : other;
-                if (filters[i] == ORC_SHUFFLE) orc_unshuffle(ts, bsize, cur, out);
-                else orc_bitunshuffle(ts, bsize, cur, out);
-                other = cur; cur = out;
-            }
-        }
+        const int r = decode_one_block(src, cbytes, blocksize, nblocks, leftover, ts, dont_split, compformat, j, dst, tmpa, tmpb);
+        if (r < 0) { rc = r; break; }
     }
-done:
     free(tmpa);
     return rc;
 }

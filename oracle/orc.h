@@ -52,7 +52,7 @@ typedef struct {
     int32_t clevel;      /* 0..9 */
     int32_t typesize;    /* sizeof(T) */
     int32_t blocksize;   /* requested block size in bytes (0 unsupported: the reference always sets it) */
-    int32_t compcode;    /* ORC_LZ4 or ORC_BLOSCLZ (lz4hc / zstd: decode of format 1 only, no encoder restated) */
+    int32_t compcode;    /* ORC_LZ4 or ORC_BLOSCLZ restated; ORC_ZSTD through the box's libzstd (zstd_dl.c); lz4hc: decode only */
     int32_t splitmode;   /* ORC_AUTO_SPLIT is what the reference uses (wrapper.h:328,353) */
     uint8_t filters[ORC_MAX_FILTERS];      /* default {0,0,0,0,0,ORC_SHUFFLE} */
     uint8_t filters_meta[ORC_MAX_FILTERS];
@@ -77,6 +77,13 @@ int orc_blosclz_decompress(const uint8_t* src, int csize, uint8_t* dst, int cap)
 int orc_blosclz_probe(const uint8_t* src, int maxlen, int force_3b_shift);
 int orc_blosclz_plan(int clevel, const uint8_t* src, int n);
 
+/* ---- zstd streams through the box's own libzstd (zstd_dl.c; dlopen, nothing restated) ---- */
+int orc_zstd_available(void);
+const char* orc_zstd_version(void);
+int orc_zstd_level_of_clevel(int clevel);
+int orc_zstd_compress_stream(int clevel, const uint8_t* src, int n, uint8_t* dst, int maxout);   /* 0 = does not fit */
+int orc_zstd_decompress_stream(const uint8_t* src, int csize, uint8_t* dst, int cap);
+
 /* ---- filters (filters.c) ---- */
 void orc_shuffle(int typesize, int bsize, const uint8_t* src, uint8_t* dst);
 void orc_unshuffle(int typesize, int bsize, const uint8_t* src, uint8_t* dst);
@@ -92,6 +99,8 @@ int orc_blosc2_compress(const orc_cparams* p, const void* src, int32_t nbytes, v
 int orc_blosc2_compress_2phase(const orc_cparams* p, const void* src, int32_t nbytes, void* dst,
                                int32_t destsize, int nthreads);
 int orc_blosc2_decompress(const void* src, int32_t srcsize, void* dst, int32_t destsize);
+/* the same with the blocks of the chunk spread over nthreads OpenMP threads (bench.py's all-cores CPU baseline only) */
+int orc_blosc2_decompress_mt(const void* src, int32_t srcsize, void* dst, int32_t destsize, int nthreads);
 int orc_blosc2_cbuffer_sizes(const void* cbuffer, int32_t* nbytes, int32_t* cbytes, int32_t* blocksize);
 
 /* Derived geometry, exposed for tests. */

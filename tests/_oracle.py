@@ -33,7 +33,7 @@ class Geometry(C.Structure):
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(_LIB)
-            for f in ("lz4_block.c", "filters.c", "chunk.c", "orc.h", "blosclz.c")
+            for f in ("lz4_block.c", "filters.c", "chunk.c", "orc.h", "blosclz.c", "zstd_dl.c", "bench_cpu.c")
             if os.path.exists(os.path.join(ORACLE_DIR, f))):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
     return _LIB
@@ -72,6 +72,9 @@ def lib():
         L.orc_blosc2_cbuffer_sizes.restype = C.c_int
         L.orc_chunk_geometry.argtypes = [C.POINTER(CParams), C.c_int32, C.POINTER(Geometry)]
         L.orc_chunk_geometry.restype = C.c_int
+        L.orc_zstd_available.restype = C.c_int
+        L.orc_zstd_version.restype = C.c_char_p
+        L.orc_zstd_level_of_clevel.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -167,6 +170,15 @@ def decompress(chunk, nbytes=None):
     out = np.zeros(max(nbytes, 1), dtype=np.uint8)
     r = lib().orc_blosc2_decompress(_ptr(c), c.size, _ptr(out), nbytes)
     return r, out[:max(r, 0)]
+
+
+def zstd_available():
+    """The box has a libzstd the checker can dlopen (oracle/zstd_dl.c): ORC_ZSTD chunks can be made and decoded."""
+    return bool(lib().orc_zstd_available())
+
+
+def zstd_version():
+    return lib().orc_zstd_version().decode()
 
 
 def cbuffer_sizes(chunk):

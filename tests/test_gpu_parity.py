@@ -825,3 +825,48 @@ def test_mutated_zstd_chunks_fail_or_decode_but_never_hang(eng, golden_dir):
         outs, status = eng.decompress_host(batch, check=False)
         assert status[0] == 0 and outs[0].tobytes() == want
         assert (status <= 0).all()
+
+
+def test_config5_zstd_full_size_one_rank_share(eng):
+    """BASELINE configs[4] as named, one rank's share: ONE 16384 x 16384 float32 channel = 256 chunks x 4 MiB = 32768 blocks of
+    32 KiB, zstd + byte shuffle (enums.h:18-24; blosc2/wrapper.h:236-259).  The chunks are made here by the box's libzstd under
+    the checker's chunk layer (oracle/zstd_dl.c) the way c-blosc2 frames them: the whole GiB at a fast level (clevel 3: split
+    planes, 131072 frames) in ONE device-resident decode call, and a 32-chunk slice at the reference's default clevel 9
+    (= ZSTD_maxCLevel(), one unsplit frame per block).  Pixels must come back bit-exact; the ratio is printed."""
+    if not O.zstd_available():
+        pytest.skip("no libzstd on this box")
+    import ctypes as C
+    W = H = 16384
+    chan = synth.tiled_channel(np.float32, W, H)
+    host = chan.view(np.uint8).ravel()
+    CH = 4 << 20
+    L = O.lib()
+    L.orc_bench_compress.argtypes = [C.POINTER(O.CParams), C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int, C.c_int]
+    L.orc_bench_compress.restype = C.c_int64
+    threads = min(len(os.sched_getaffinity(0)), 16)
+
+    def make(first, count, clevel):
+        stride = CH + 64
+        comp = np.zeros(count * stride, np.uint8)
+        cb = np.zeros(count, np.int32)
+        p = O.cparams(4, clevel=clevel, blocksize=32768, compcode=O.ZSTD)
+        r = L.orc_bench_compress(C.byref(p), host[first * CH:].ctypes.data, count, CH, comp.ctypes.data, stride, CH + 32, cb.ctypes.data,
+                                 min(threads, count), max(1, threads // min(threads, count)))
+        assert r > 0
+        return comp, cb, stride
+
+    for first, count, clevel in ((0, 256, 3), (96, 32, 9)):
+        comp, cb, stride = make(first, count, clevel)
+        n = count * CH
+        d_comp = eng.alloc(comp.size)
+        d_comp.upload(comp)
+        d_raw = eng.alloc(n)
+        st = eng.decompress_device(d_comp.ptr, np.arange(count, dtype=np.int64) * stride, [CH] * count, [32768] * count,
+                                   d_raw.ptr, np.arange(count, dtype=np.int64) * CH, comp_size=cb)
+        assert not st.any()
+        got = d_raw.download(n)
+        assert got.tobytes() == host[first * CH:first * CH + n].tobytes(), clevel
+        flags = comp[2]
+        assert (flags >> 5) == 4 and bool(flags & 0x10) == (clevel > 5)          # codec format 4; unsplit above clevel 5
+        print(f"configs[4] share: {count} chunks at zstd clevel {clevel}: ratio {n / float(cb.sum()):.3f}")
+        d_comp.free(); d_raw.free()
