@@ -121,7 +121,7 @@ def test_truncated_device_resident_chunk_is_refused():
     off2 = (n + 63) & ~63
     d_comp.upload(np.frombuffer(good, np.uint8), off2)
     d_raw = e.alloc(2 * a.nbytes)
-    nb, bs, _ = hip.cbuffer_sizes(good)
+    nb, _, bs = hip.cbuffer_sizes(good)
     # both chunks as they are
     st = e.decompress_device(d_comp.ptr, [0, off2], [nb, nb], [bs, bs], d_raw.ptr, [0, a.nbytes], comp_size=[n, n])
     assert not st.any()
