@@ -74,17 +74,13 @@ extern "C" __global__ __launch_bounds__(256) void cimg_emit_blocks(AssembleArgs 
     eb.run(__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
 
-extern "C" __global__ __launch_bounds__(256) void cimg_decode_lean(DecodeArgs a)
+// persistent: one wave per workgroup owns one LDS plane and walks blocks blockIdx.x, + gridDim.x, ... (decode_lean_kernel.h).
+// Two waves per SIMD (the stored plane of a block travels through its chain in 64 VGPRs): at most 256 registers.
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void cimg_decode_lean(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    DecodeLean blk(a, lds, (int)blockIdx.x);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = (int)(blockDim.x >> 6);
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
-    blk.phase_a(wave, nwaves);                                   // stamps 1 / 2 inside: header walk done, coded bytes staged
-    __syncthreads();
-    blk.phase_b(wave, nwaves);
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
+    DecodeLeanWave w(a, lds);
+    w.run((int)blockIdx.x, (int)gridDim.x);
 }
 
 // blocks of zstd-coded chunks, one wave per block: the slow path that keeps chunks written with enums::codec::zstd readable
@@ -94,44 +90,6 @@ extern "C" __global__ __launch_bounds__(64) void cimg_decode_zstd(DecodeArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     DecodeZstdBlock blk(a, lds, (int)blockIdx.x);
     blk.run();
-}
-
-// the lean launch with TWO waves per block: wave 0 finds the tokens of the LZ4 chain, wave 1 moves the bytes (decode_pair.h)
-extern "C" __global__ __launch_bounds__(128) void cimg_decode_lean_pair(DecodeArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    DecodeLean blk(a, lds, (int)blockIdx.x);
-    blk.pair_mode = 1;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
-    blk.phase_a(wave, 2);
-    __syncthreads();
-    if (blk.pair_on) {
-        // both waves reach the barrier of every step; a step consumes input or ends the stream, so csize + 2 steps is a hard bound
-        unsigned long long t_work = 0, t_bar = 0;                   // diagnostics (a.dbg != nullptr only)
-        int steps = 0;
-        for (int step = 0; step <= blk.lz_cs + 2; ++step) {
-            const unsigned long long c0 = a.dbg ? cimg_cycles() : 0;
-            if (wave == 0) blk.prod.compute(step);
-            else lz4_pair_consume(lds, 0, blk.mail + ((step + 1) & 1) * PAIR_SLOT_BYTES, blk.mail);
-            const unsigned long long c1 = a.dbg ? cimg_cycles() : 0;
-            __syncthreads();
-            t_work += c1 - c0; t_bar += (a.dbg ? cimg_cycles() : 0) - c1;
-            ++steps;
-            if (mail_hdr(lds, blk.mail + (step & 1) * PAIR_SLOT_BYTES, 0) == PAIR_END) break;
-        }
-        if (a.dbg && __lane_id() == 0) {
-            uint64_t* d = a.dbg + 16 * (size_t)blockIdx.x + 4 + 4 * wave;      // stamp slots 1 (wave 0) and 2 (wave 1)
-            d[0] = t_work; d[1] = 0; d[2] = t_bar; d[3] = (uint64_t)steps;
-#ifdef CIMG_PAIR_PROF
-            if (wave == 0) { uint64_t* q = a.dbg + 16 * (size_t)blockIdx.x; d[1] = blk.prod.t_parse; q[2] = blk.prod.t_post; q[3] = blk.prod.t_scalar; }
-#endif
-        }
-        if (wave == 0) blk.pair_finish();
-        __syncthreads();
-    }
-    blk.phase_b(wave, 2);
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
@@ -198,7 +156,8 @@ struct cimg_engine {
     bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
     // decode: the lean kernel (decode_lean_kernel.h) runs in front of the general one while it pays off
     DevBuf done;                        // uint32 per block: generation stamp of the lean kernel
-    int lean_threads = getenv("CIMG_LEAN_THREADS") ? atoi(getenv("CIMG_LEAN_THREADS")) : 64;              // one wave per block (measured best; 64 / 128 / 256 are valid)
+    int lean_wgs_cu = 0, lean_wgs_lds = -1;   // resident lean decode waves per CU for that much LDS (occupancy query, cached)
+    int lean_wgs_limit = getenv("CIMG_LEAN_WGS_PER_CU") ? atoi(getenv("CIMG_LEAN_WGS_PER_CU")) : 0;   // diagnostic: fewer persistent waves
     uint32_t done_gen = 0;
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
     int64_t zstd_batches = 0;           // decode batches that needed cimg_decode_zstd
@@ -221,8 +180,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    bool lean_pair = getenv("CIMG_LEAN_PAIR") != nullptr && atoi(getenv("CIMG_LEAN_PAIR")) != 0;   // two waves per lean block (decode_pair.h)
-    int max_dyn_lds[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / lean pair / zstd
+    int max_dyn_lds[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / (unused) / zstd
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -746,33 +704,31 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     const bool timed = e->timing;
     if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
     if (lean) {
-        const bool pair = e->lean_pair;
-        const int lean_lds = pair ? plan.lds_lean_pair : plan.lds_lean;
-        DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, lean_lds, dbg,
-                      plan.uniform_nblocks, done, e->done_gen, skipped_dev};
-        if (e->verbose && !e->lean_batches) {
-            int per_cu = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean, e->lean_threads, (size_t)plan.lds_lean);
-            fprintf(stderr, "[cimg] lean decode launch: %d bytes LDS, %d threads -> %d workgroups per CU\n", plan.lds_lean, e->lean_threads, per_cu);
-        }
-        if (pair) {
-            if (e->verbose && !e->lean_batches) {
+        // persistent waves, as many as are resident at once (registers: two per SIMD; LDS: 1280-byte granules per workgroup),
+        // never more than there are blocks; wave w walks blocks w, w + G, ...
+        if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean))) {
+            if (e->lean_wgs_lds != plan.lds_lean) {
                 int per_cu = 0;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cimg_decode_lean_pair), hipFuncAttributeMaxDynamicSharedMemorySize, lean_lds);
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean_pair, 128, (size_t)lean_lds);
-                fprintf(stderr, "[cimg] lean pair decode launch: %d bytes LDS, 128 threads -> %d workgroups per CU\n", lean_lds, per_cu);
+                if ((rc = e->hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cimg_decode_lean, 64, (size_t)plan.lds_lean), "occupancy query"))) return rc;
+                const int granules = (plan.lds_lean + LDS_GRANULE - 1) / LDS_GRANULE;
+                e->lean_wgs_cu = std::max(1, std::min(per_cu, e->lds_per_cu / LDS_GRANULE / std::max(granules, 1)));
+                e->lean_wgs_lds = plan.lds_lean;
+                if (e->verbose) fprintf(stderr, "[cimg] lean decode launch: %d bytes LDS -> %d persistent waves per CU (occupancy query %d)\n", plan.lds_lean, e->lean_wgs_cu, per_cu);
             }
-            if (!(rc = e->allow_lds(cimg_decode_lean_pair, 4, lean_lds)))
-                rc = e->launch(CIMG_K_DECODE, cimg_decode_lean_pair, la, plan.total_blocks, 128, lean_lds);
-        } else if (!(rc = e->allow_lds(cimg_decode_lean, 2, plan.lds_lean)))
-            rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, plan.total_blocks, e->lean_threads, plan.lds_lean);
+            int per_cu_use = e->lean_wgs_cu;
+            if (e->lean_wgs_limit > 0) per_cu_use = std::max(1, std::min(per_cu_use, e->lean_wgs_limit));
+            const int grid = std::min(plan.total_blocks, per_cu_use * e->num_cus);
+            DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, dbg,
+                          plan.uniform_nblocks, done, e->done_gen, skipped_dev, plan.total_blocks};
+            rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, grid, 64, plan.lds_lean);
+        }
     }
     // The general kernel goes right behind the lean one -- unless the previous lean batch left it nothing to do: then
     // it is only launched (and waited for) if the skipped count that comes back says a block is still undecoded.
     const bool general_now = !lean || e->lean_last_skipped != 0;
     // (diagnostic stamps go to the lean launch when there is one: both would write the same slots)
     DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, (lean && stamping) ? nullptr : dbg,
-                  plan.uniform_nblocks, done, e->done_gen, nullptr};
+                  plan.uniform_nblocks, done, e->done_gen, nullptr, plan.total_blocks};
     if (!rc && general_now) {
         if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);

@@ -166,7 +166,6 @@ struct DecodePlan {
     int32_t total_blocks = 0;
     int32_t lds_bytes = 0;
     int32_t lds_lean = 0;        // LDS of the lean launch: one plane of a 2-byte type (0: blocks too large for it)
-    int32_t lds_lean_pair = 0;   // the same plus the mailbox of the two-wave form (decode_pair.h)
     int32_t uniform_nblocks = 0;
 };
 
@@ -208,7 +207,6 @@ inline int plan_decode_batch(int nchunks, const int64_t* comp_off, const int32_t
     plan->total_blocks = blk;
     plan->lds_bytes = lds;
     plan->lds_lean = blz_region_stride(max_bs / 2) + 16;      // decode_lean_kernel.h: the one coded plane of a block (the larger, BloscLZ margin)
-    plan->lds_lean_pair = plan->lds_lean + PAIR_MAIL_BYTES + 16;
     plan->uniform_nblocks = uniform_blocks(plan->descs);
     return 0;
 }

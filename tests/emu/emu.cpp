@@ -78,7 +78,7 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
 }
 
 extern "C" void emu_set_block_items(int on) { g_emu_block_items = on; }
-int g_emu_lean_shape = -1;      // -1: rotate over the launch shapes of the lean kernel, else force one (0 / 1 / 2)
+int g_emu_lean_shape = -1;      // <= 0: rotate the number of persistent lean waves (1, 3, 7, one per block), else that many
 extern "C" void emu_set_lean_shape(int shape) { g_emu_lean_shape = shape; }
 int g_emu_lean = 1;            // tests switch the lean kernel off to cover the general one on every block
 long g_emu_lean_blocks = 0;    // blocks the lean kernel produced since the last emu_stats reset
@@ -97,42 +97,21 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     std::vector<uint32_t> done((size_t)plan.total_blocks, 0);
     const uint32_t gen = 7;
     if (g_emu_lean) {
-        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr};
-        DecodeArgs lp = la;
-        lp.lds_bytes = plan.lds_lean_pair;
-        std::vector<uint8_t> llds((size_t)plan.lds_lean_pair + EMU_LDS_SLACK);
-        for (int b = 0; b < plan.total_blocks; b++) {
+        // cimg_decode_lean: persistent waves; wave w of G walks blocks w, w + G, ... with the loads of the next two blocks issued
+        // ahead (here they simply happen early).  G rotates so that one-, two- and many-block walks are all covered.
+        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr, plan.total_blocks};
+        std::vector<uint8_t> llds((size_t)plan.lds_lean + EMU_LDS_SLACK);
+        static int rot = 0;
+        const int choices[4] = {1, 3, 7, plan.total_blocks > 0 ? plan.total_blocks : 1};
+        const int G = g_emu_lean_shape > 0 ? g_emu_lean_shape : choices[rot++ & 3];
+        for (int w = 0; w < G && w < plan.total_blocks; w++) {
             memset(llds.data(), 0xCD, llds.size());
-            const int shape = g_emu_lean_shape >= 0 ? g_emu_lean_shape : b % 3;   // one wave, four waves, the two-wave pair
-            if (shape == 2) {
-                // cimg_decode_lean_pair: both waves walk the header; then the step loop with its two barriers
-                memset(llds.data(), 0, llds.size());                 // a stale mailbox reads as "batch": init() must overwrite it
-                DecodeLean blk(lp, llds.data(), b);
-                blk.pair_mode = 1;
-                DecodeLean w0 = blk, w1 = blk;
-                w0.phase_a(0, 2); w1.phase_a(1, 2);
-                if (w0.pair_on) {
-                    for (int step = 0; step <= (1 << 20); ++step) {
-                        const int theirs = w1.mail + ((step + 1) & 1) * PAIR_SLOT_BYTES;
-                        if ((step >> 1) & 1) { w0.prod.compute(step); lz4_pair_consume(llds.data(), 0, theirs, w1.mail); }   // either order: the two touch disjoint bytes
-                        else { lz4_pair_consume(llds.data(), 0, theirs, w1.mail); w0.prod.compute(step); }
-                        if (mail_hdr(llds.data(), w0.mail + (step & 1) * PAIR_SLOT_BYTES, 0) == PAIR_END) break;
-                    }
-                    w0.pair_finish();
-                }
-                w0.phase_b(0, 2); w1.phase_b(1, 2);
-            } else {
-                DecodeLean blk(la, llds.data(), b);
-                DecodeLean w0 = blk, w1 = blk, w2 = blk, w3 = blk;
-                DecodeLean* ws[4] = {&w0, &w1, &w2, &w3};
-                const int nw = shape == 1 ? 4 : 1;
-                for (int w = 0; w < nw; w++) ws[w]->phase_a(w, nw);
-                for (int w = 0; w < nw; w++) ws[w]->phase_b(w, nw);
-            }
-            if (done[(size_t)b] == gen) g_emu_lean_blocks++;
+            DecodeLeanWave wave(la, llds.data());
+            wave.run(w, G);
         }
+        for (int b = 0; b < plan.total_blocks; b++) if (done[(size_t)b] == gen) g_emu_lean_blocks++;
     }
-    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr};
+    DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr, plan.total_blocks};
     for (int b = 0; b < plan.total_blocks; b++) {
         memset(lds.data(), 0xCD, lds.size());
         DecodeBlock blk(da, lds.data(), b);

@@ -438,38 +438,6 @@ def test_device_batches_in_two_steps_overlap_and_refuse_misuse(eng):
     eng.synchronize()
 
 
-def test_two_wave_lean_decode_gives_the_same_pixels():
-    """CIMG_LEAN_PAIR=1 (read when an engine is created): the lean decode launch with two waves per block -- wave 0 finds
-    the tokens of the LZ4 chain, wave 1 moves the bytes (csrc/decode_pair.h).  Same pixels, same verdicts on damaged chunks."""
-    os.environ["CIMG_LEAN_PAIR"] = "1"
-    try:
-        e2 = hip.Engine(0)
-    finally:
-        del os.environ["CIMG_LEAN_PAIR"]
-    try:
-        for dtype, arr in ((np.float16, synth.tiled_channel(np.float16, 4096, 256)), (np.uint16, synth.tiled_channel(np.uint16, 2048, 128)),
-                           (np.float16, synth.natural_channel(np.float16, 1024, 100)), (np.float32, synth.tiled_channel(np.float32, 1024, 64))):
-            _roundtrip(e2, dtype, arr, 4 * 1024 * 1024)
-            _roundtrip(e2, dtype, arr, 100000 // np.dtype(dtype).itemsize * np.dtype(dtype).itemsize)
-        a = synth.tiled_channel(np.float16, 2048, 64)
-        (good,) = e2.compress_host(hip.cparams(2), a, [a.nbytes], [a.nbytes + 32])
-        rng = np.random.default_rng(21)
-        for _ in range(40):
-            bad = bytearray(good)
-            bad[int(rng.integers(32 + 16, len(bad)))] ^= 1 << int(rng.integers(0, 8))
-            r, pix = O.decompress(bytes(bad), a.nbytes)
-            try:
-                outs, status = e2.decompress_host([bytes(bad)])
-                ok = not status.any()
-            except hip.CodecError:
-                ok = False
-            assert ok == (r == a.nbytes)
-            if ok:
-                assert outs[0].tobytes() == pix.tobytes()
-    finally:
-        e2.close()
-
-
 def test_lean_and_general_decode_agree_on_mixed_batches(eng):
     """One batch holding chunks the lean kernel takes (tiled float16), chunks it must leave (both planes coded, ragged
     leftover blocks, typesize 1) and a damaged chunk: every good chunk decodes, the damaged one is reported."""
