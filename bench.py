@@ -429,7 +429,8 @@ def main():
         return cb
 
     cbytes = step()
-    if not torch.equal(d_out, d_raw):
+    no_verify = bool(os.environ.get("CIMG_BENCH_NO_VERIFY"))       # kernel-timing experiments with deliberately broken builds only
+    if not torch.equal(d_out, d_raw) and not no_verify:
         print("bench.py: decompressed pixels differ from the input -- refusing to report a number", file=sys.stderr)
         sys.exit(3)
     for _ in range(args.warmup):
@@ -494,7 +495,7 @@ def main():
                         "exchange_GBps": round(moved / float(tmax.item()) / 1e9, 3) if moved else None,
                         "backend": "gloo (rehearsal on one GPU: meaningless as a number)" if rehearsal else "nccl (RCCL over xGMI)",
                         "complete": bool(ok)}
-    if not torch.equal(d_out, d_raw):
+    if not torch.equal(d_out, d_raw) and not no_verify:
         print("bench.py: pixels differ after the timed region", file=sys.stderr)
         sys.exit(3)
 
@@ -515,7 +516,7 @@ def main():
         traffic, traffic_src = pmc_traffic(hip.KERNELS[dom], args.pmc_json) if headline else (None, None)
         dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE], args.pmc_json) if headline else (None, None)
         out = {
-            "metric": "compress+decompress GB/s (uncompressed side)",
+            "metric": "compress+decompress GB/s (uncompressed side)" + (" -- INVALID: pixels not verified (CIMG_BENCH_NO_VERIFY)" if no_verify else ""),
             "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3),
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

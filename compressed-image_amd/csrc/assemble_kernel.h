@@ -28,7 +28,7 @@ struct AssembleArgs {
     ChunkLayout* layout;       // per chunk
     int32_t uniform_nblocks;   // > 0: every chunk has this many blocks
     ChunkLayout* layout_host;  // optional second copy of `layout` in pinned host memory (read by the host after the sync)
-    uint32_t* queue;           // optional: the encode work-queue heads (words 0 and 4), zeroed here for the next batch
+    int32_t skip_assembled;    // 1 (the stand-alone kernels behind an assembling encode launch): chunks with ChunkDesc::assemble are done already
 };
 
 CIMG_DEV int rec_payload(const StreamRec& r) { return r.kind == REC_RUN ? (r.value > 0 ? 1 : 0) : r.csize; }
@@ -36,6 +36,10 @@ CIMG_DEV int rec_payload(const StreamRec& r) { return r.kind == REC_RUN ? (r.val
 struct LayoutChunk {
     const AssembleArgs& a;
     int chunk;
+    // inside the encode launch (encode_kernel.h): what this wave writes -- bstarts, header, the layout word -- is read by waves on
+    // other XCDs before the launch ends, so it is written THROUGH to memory (agent-scope stores) instead of being written back by
+    // an L2 flush afterwards; possible when the chunk starts on a 4-byte boundary (the caller checks)
+    bool through = false;
     CIMG_DEV LayoutChunk(const AssembleArgs& a_, int chunk_) : a(a_), chunk(chunk_) {}
 
     CIMG_DEV void write_header(const ChunkDesc& d, uint8_t* c, int flags, int cbytes, int blosc2_flags)
@@ -55,12 +59,28 @@ struct LayoutChunk {
             else if (l == OFF_BLOSC2_FLAGS) v = (uint32_t)blosc2_flags;
             byte[l] = v;
         }
+        if (through) {
+            // eight dwords, lanes 0 .. 7 (the bytes of dword k sit in lanes 4 k .. 4 k + 3)
+            LV<int> src;
+            LV<uint32_t> b0, b1, b2, b3;
+            FOR_LANES(l) { src[l] = (4 * l) & 63; }
+            lane_gather(byte, src, b0);
+            FOR_LANES(l) { src[l] = (4 * l + 1) & 63; }
+            lane_gather(byte, src, b1);
+            FOR_LANES(l) { src[l] = (4 * l + 2) & 63; }
+            lane_gather(byte, src, b2);
+            FOR_LANES(l) { src[l] = (4 * l + 3) & 63; }
+            lane_gather(byte, src, b3);
+            FOR_LANES_W(l) { if (l < HEADER_LEN / 4) atomic_store_agent(reinterpret_cast<uint32_t*>(c) + l, b0[l] | (b1[l] << 8) | (b2[l] << 16) | (b3[l] << 24)); }
+            return;
+        }
         FOR_LANES(l) { if (l < HEADER_LEN) c[l] = (uint8_t)byte[l]; }
     }
 
     CIMG_DEV void run()
     {
         const ChunkDesc d = uniform_desc(a.descs + chunk);
+        if (a.skip_assembled && d.assemble) return;                       // the encode launch did this chunk itself
         uint8_t* c = a.comp + d.comp_off;
         ChunkLayout lay;
         lay.cbytes = 0; lay.mode = 3;
@@ -84,7 +104,15 @@ struct LayoutChunk {
                         const int i = imin(g0 + 64 * k + l, total - 1);
                         int jb, s;
                         if (i < nfull * per_full) { jb = i / per_full; s = i - jb * per_full; } else { jb = nfull; s = 0; }
-                        recs[k][l] = a.recs[(int64_t)(d.blk0 + jb) * a.p.streams_per_block + s];
+                        const StreamRec* rp = a.recs + (int64_t)(d.blk0 + jb) * a.p.streams_per_block + s;
+                        if (through) {
+                            // other waves' records, written through by them: read past this XCD's L2 (no invalidate needed)
+                            const uint32_t* w = reinterpret_cast<const uint32_t*>(rp);
+                            recs[k][l].kind = (int32_t)atomic_load_agent(w + 0); recs[k][l].value = (int32_t)atomic_load_agent(w + 1);
+                            recs[k][l].csize = (int32_t)atomic_load_agent(w + 2); recs[k][l].need = (int32_t)atomic_load_agent(w + 3);
+                        } else {
+                            recs[k][l] = *rp;
+                        }
                     }
                 }
                 CIMG_UNROLL
@@ -127,7 +155,7 @@ struct LayoutChunk {
                                 }
                             }
                             bad[l] = f;
-                            if (first[l]) st32(c + HEADER_LEN + 4 * blk[l], nt + pre[l]);
+                            if (first[l]) { if (through) atomic_store_agent(reinterpret_cast<uint32_t*>(c + HEADER_LEN) + blk[l], (uint32_t)(nt + pre[l])); else st32(c + HEADER_LEN + 4 * blk[l], nt + pre[l]); }
                         }
                     }
                     if (ballot(bad)) fits = false;
@@ -153,11 +181,15 @@ struct LayoutChunk {
                 if (d.destsize >= HEADER_LEN) write_header(d, c, d.flags, 0, 0);
             }
         }
-        FOR_LANES(l) {
+        FOR_LANES_W(l) {
             if (l == 0) {
-                a.layout[chunk] = lay;
+                if (through) {
+                    atomic_store_agent(reinterpret_cast<uint32_t*>(&a.layout[chunk].cbytes), (uint32_t)lay.cbytes);
+                    atomic_store_agent(reinterpret_cast<uint32_t*>(&a.layout[chunk].mode), (uint32_t)lay.mode);
+                } else {
+                    a.layout[chunk] = lay;
+                }
                 if (a.layout_host) a.layout_host[chunk] = lay;
-                if (a.queue && chunk == 0) { a.queue[0] = 0; a.queue[4] = 0; }
             }
         }
     }
@@ -168,28 +200,65 @@ struct EmitBlock {
     int b;
     CIMG_DEV EmitBlock(const AssembleArgs& a_, int b_) : a(a_), b(b_) {}
 
-    CIMG_DEV void run(int wave)
+    // the stand-alone kernel: `wave` of `nwaves` cooperating waves copy the whole block
+    CIMG_DEV void run(int wave, int nwaves = 4) { copy(wave, nwaves, 0, MAX_STREAMS); }
+    // inside the encode launch: ONE wave copies the streams [s_begin, s_end) it encoded itself.  What OTHER waves wrote -- the
+    // closer's layout word and bstarts[j], the records of the block's other streams -- is read with agent-scope loads straight from
+    // memory (the writers wrote it through / wrote it back); the payload is this wave's own and comes out of its own L2.  No
+    // acquire fence: an L2 invalidate per wave and chunk, a thousand waves at once, cost the launch more than the copies.
+    CIMG_DEV void run_streams(int s_begin, int s_end) { copy(0, 1, s_begin, s_end, true); }
+
+    CIMG_DEV void copy(int wave, int nwaves, int s_begin, int s_end, bool coherent = false)
     {
         const int chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
         const ChunkDesc d = uniform_desc(a.descs + chunk);
+        if (a.skip_assembled && d.assemble) return;                   // the encode launch did this chunk itself
         const int j = b - d.blk0;
         uint8_t* c = a.comp + d.comp_off;
-        const int mode = uni(a.layout[chunk].mode);
         const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
         const int bsize = leftover_blk ? d.leftover : d.blocksize;
+        const int ns = (d.split && !leftover_blk) ? a.p.typesize : 1;
+        const StreamRec* rp = a.recs + (int64_t)b * a.p.streams_per_block;
+        // What other waves wrote: the layout word, bstarts[j], {kind, value, csize} of the block's streams.  Coherent form: ONE
+        // round trip of agent-scope loads, lane 0 the mode, lane 1 bstarts[j], lanes 2 + 3 s .. 4 + 3 s the record of stream s
+        // (MAX_STREAMS = 16 streams: 50 lanes).  (bstarts[] is 4-byte aligned whenever the chunk is; a caller-chosen odd chunk
+        // address takes a fence instead.)
+        const bool aligned = ((uintptr_t)(c + HEADER_LEN) & 3) == 0;
+        LV<int32_t> meta;
+        if (coherent) {
+            if (!aligned) fence_acquire();
+            FOR_LANES(l) {
+                const int k = l - 2, sidx = k >= 0 ? k / 3 : 0, f = k >= 0 ? k - 3 * sidx : 0;
+                const uint32_t* p = l == 0 ? reinterpret_cast<const uint32_t*>(&a.layout[chunk].mode)
+                                  : l == 1 ? reinterpret_cast<const uint32_t*>(c + HEADER_LEN + (aligned ? 4 * j : 0))
+                                           : reinterpret_cast<const uint32_t*>(rp + (sidx < ns ? sidx : 0)) + f;
+                meta[l] = (l == 1 && !aligned) ? ld32s(c + HEADER_LEN + 4 * j) : (int32_t)atomic_load_agent(p);
+            }
+        } else {
+            FOR_LANES(l) {
+                const int k = l - 2, sidx = k >= 0 ? k / 3 : 0, f = k >= 0 ? k - 3 * sidx : 0;
+                const StreamRec& r = rp[sidx < ns ? sidx : 0];
+                meta[l] = l == 0 ? a.layout[chunk].mode : l == 1 ? ld32s(c + HEADER_LEN + 4 * j) : (f == 0 ? r.kind : f == 1 ? r.value : r.csize);
+            }
+        }
+        const int mode = readlane(meta, 0);
         if (mode == 1) {
-            wave_copy_g2g(a.raw + d.raw_off + (int64_t)j * d.blocksize, c + HEADER_LEN + (int64_t)j * d.blocksize, bsize, wave, 4);
+            // memcpyed chunk: the raw pixels of the block; a caller that owns streams [s_begin, s_end) of ns copies that share of them
+            const int lo = s_begin <= 0 ? 0 : (int)((int64_t)bsize * s_begin / ns) & ~15;
+            const int hi = s_end >= ns ? bsize : (int)((int64_t)bsize * s_end / ns) & ~15;
+            const int64_t at = (int64_t)j * d.blocksize + lo;
+            if (hi > lo) { if (nwaves == 1) wave_copy_g2g<16>(a.raw + d.raw_off + at, c + HEADER_LEN + at, hi - lo, 0, 1); else wave_copy_g2g(a.raw + d.raw_off + at, c + HEADER_LEN + at, hi - lo, wave, nwaves); }
             return;
         }
         if (mode != 0) return;
-        const int ns = (d.split && !leftover_blk) ? a.p.typesize : 1;
         const int neblock = bsize / ns;
         const uint8_t* slot = a.scratch + (int64_t)b * a.p.slot_bytes;
-        int pos = uni(ld32s(c + HEADER_LEN + 4 * j));
-        for (int s = 0; s < ns; s++) {
-            StreamRec r = a.recs[(int64_t)b * a.p.streams_per_block + s];
-            r.kind = uni(r.kind); r.value = uni(r.value); r.csize = uni(r.csize);
-            if (wave == 0) {
+        int pos = readlane(meta, 1);
+        for (int s = 0; s < ns && s < s_end && s < MAX_STREAMS; s++) {
+            StreamRec r;
+            r.kind = readlane(meta, 2 + 3 * s); r.value = readlane(meta, 3 + 3 * s); r.csize = readlane(meta, 4 + 3 * s); r.need = 0;
+            const bool mine = s >= s_begin;
+            if (wave == 0 && mine) {
                 const int word = r.kind == REC_RUN ? -r.value : r.csize;
                 FOR_LANES(l) {
                     if (l < 4) c[pos + l] = (uint8_t)(((uint32_t)word >> (8 * l)) & 0xFF);
@@ -197,7 +266,7 @@ struct EmitBlock {
                 }
             }
             pos += 4;
-            if (r.kind != REC_RUN) wave_copy_g2g(slot + (int64_t)s * neblock, c + pos, r.csize, wave, 4);
+            if (r.kind != REC_RUN && mine) { if (nwaves == 1) wave_copy_g2g<16>(slot + (int64_t)s * neblock, c + pos, r.csize, 0, 1); else wave_copy_g2g(slot + (int64_t)s * neblock, c + pos, r.csize, wave, nwaves); }
             pos += rec_payload(r);
         }
     }

@@ -43,6 +43,8 @@ struct ChunkDesc {
     int32_t split;        // 1: full blocks are cut into `typesize` streams
     int32_t memcpyed;     // 1: clevel 0 or nbytes < 32 -> header + raw bytes
     int32_t nstreams;     // total stream count of the chunk
+    int32_t assemble;     // encode: 1 = every stream of the chunk belongs to ONE encode launch, which then lays the chunk out and copies it into place itself
+    int32_t pad_;
 };
 
 // batch-wide codec parameters

@@ -82,7 +82,7 @@ CIMG_DEV ChunkDesc uniform_desc(const ChunkDesc* p)
     d.raw_off = uni64(d.raw_off); d.comp_off = uni64(d.comp_off);
     d.nbytes = uni(d.nbytes); d.destsize = uni(d.destsize); d.blocksize = uni(d.blocksize); d.nblocks = uni(d.nblocks);
     d.leftover = uni(d.leftover); d.blk0 = uni(d.blk0); d.flags = uni(d.flags); d.split = uni(d.split);
-    d.memcpyed = uni(d.memcpyed); d.nstreams = uni(d.nstreams);
+    d.memcpyed = uni(d.memcpyed); d.nstreams = uni(d.nstreams); d.assemble = uni(d.assemble);
     return d;
 }
 
@@ -143,12 +143,14 @@ CIMG_DEV void wave_fill_lds(uint8_t* lds, int off, int nbytes, uint32_t byte)
     }
 }
 
-// global -> global, used for memcpyed chunks; 256 threads = 4 waves, wave w takes every 4th KiB
+// global -> global, used for memcpyed chunks; 256 threads = 4 waves, wave w takes every 4th KiB.
+// DEPTH 16-byte loads per lane are in flight before the first store (a copy with one is pure HBM latency): four where four waves
+// share a block, sixteen -- a whole 16 KiB plane in one round trip -- where ONE wave copies its streams inside the encode launch
+// (a wave alone copies 17 KiB in five round trips of ~2 us at depth four: the tail of the launch).
+template <int DEPTH = 4>
 CIMG_DEV void wave_copy_g2g(const uint8_t* src, uint8_t* dst, int nbytes, int wave, int nwaves)
 {
     const int units = nbytes >> 4;
-    // four 16-byte loads per lane are in flight before the first store (a copy with one is pure HBM latency)
-    constexpr int DEPTH = 4;
     const int stride = nwaves * 64;
     int u0 = wave * 64;
     for (; u0 + (DEPTH - 1) * stride + 64 <= units; u0 += DEPTH * stride) {

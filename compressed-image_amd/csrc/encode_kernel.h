@@ -36,6 +36,7 @@
 #include "wave.h"
 #include "decode_kernel.h"   // round16, find_chunk, byte_perm, wave copies
 #include "blosclz_kernel.h"
+#include "assemble_kernel.h"  // LayoutChunk / EmitBlock: run by the waves of the encode launch when the batch is assembled in place
 
 namespace cimg {
 
@@ -55,6 +56,23 @@ struct EncodeArgs {
     int32_t block_items;      // split launch only: the first `block_items` blocks are handed out WHOLE -- read from HBM once, the
                               // byte planes encoded one after the other by the same wave (the planes that wait sit in registers);
                               // the blocks behind them plane by plane
+    uint32_t queue_base;      // the queue head counts on from batch to batch: item = pop - queue_base (nothing resets it in between)
+    // ---- chunks assembled INSIDE the launch (assemble != 0; round 3) ---------------------------------------------------------
+    // A wave remembers the items it encoded (a linked list through next_item[]); the wave that finishes the last stream of a
+    // chunk lays the chunk out (LayoutChunk: bstarts, header, the running-destsize rule) and raises ready[chunk]; when the work
+    // queue is empty every wave copies ITS OWN streams from the scratch slots into place -- out of its own XCD's L2, in the time
+    // the launch's tail leaves most waves idle anyway (4096 coded planes on 1280 chains: a fifth of the chains work through a
+    // fourth plane while the rest are done).  Only chunks whose descriptor says so (ChunkDesc::assemble: every stream of the chunk
+    // belongs to ONE launch) take part; cimg_layout_chunks / cimg_emit_blocks run behind the launch for the others.
+    int32_t assemble;
+    uint8_t* comp;            // chunks are written at comp + desc.comp_off
+    ChunkLayout* layout;      // per chunk (device)
+    ChunkLayout* layout_host; // the same in page-locked host memory, plus ONE extra entry [nchunks] whose cbytes turns negative when
+                              // a wave gave up waiting for a chunk to be laid out (the host then fails the batch loudly)
+    uint32_t* chunk_count;    // per chunk: streams finished so far (the closer puts 0 back)
+    uint32_t* ready;          // per chunk: == gen once the chunk is laid out
+    int32_t* next_item;       // per item of this launch: the item the same wave encoded before it (-1: none)
+    uint32_t gen;
 };
 
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
@@ -839,6 +857,147 @@ CIMG_DEV void wave_copy_l2g(const uint8_t* lds, int off, uint8_t* g, int nbytes)
     FOR_LANES(l) { if (done + l < nbytes) g[done + l] = lds[off + done + l]; }
 }
 
+// ---- chunks assembled inside the encode launch (EncodeArgs::assemble) ----------------------------------------------------------
+// Out of line on the GPU: these run once per work item / once per wave, outside the codec loop, and inlined they cost the
+// codec loop registers (the LZ4 kernel sits at the 256-VGPR ceiling: with them inlined it spilled to scratch).
+CIMG_DEV AssembleArgs assemble_args(kernarg_ptr<EncodeArgs> ap)
+{
+    const auto a = fresh(ap);
+    AssembleArgs aa;
+    aa.descs = a->descs; aa.nchunks = a->nchunks; aa.raw = a->raw;
+    aa.p.typesize = a->p.typesize; aa.p.clevel = a->p.clevel; aa.p.compcode = a->p.compcode; aa.p.filter = a->p.filter; aa.p.accel = a->p.accel;
+    aa.p.max_blocksize = a->p.max_blocksize; aa.p.slot_bytes = a->p.slot_bytes; aa.p.streams_per_block = a->p.streams_per_block;
+    aa.scratch = a->scratch; aa.recs = a->recs;
+    aa.comp = a->comp; aa.layout = a->layout; aa.uniform_nblocks = a->uniform_nblocks; aa.layout_host = a->layout_host; aa.skip_assembled = 0;
+    return aa;
+}
+
+// block and stream of a work item (encode_items)
+CIMG_DEV void encode_item_place(kernarg_ptr<EncodeArgs> a, int item, int& b, int& s)
+{
+    const int whole = a->want_split ? a->block_items : a->total_blocks;
+    if (item < whole) {
+        b = item; s = 0;
+    } else {
+        const int rest = a->total_blocks - whole, idx = item - whole;
+        b = whole + idx % rest;
+        s = a->p.streams_per_block - 1 - idx / rest;
+    }
+}
+
+// `finished` streams of `chunk` are done: their payloads sit in the scratch slots (plain stores: only this wave reads them again),
+// their records were written through to memory (agent-scope stores).  Counts them; the wave whose streams complete the chunk lays
+// it out and raises ready[chunk].  Returns the new head of the wave's item list (the item is only remembered when its chunk is
+// assembled in the launch).
+CIMG_DEV_OUTLINE int encode_account(kernarg_ptr<EncodeArgs> ap_in, int item_in, int last_in, int chunk_in, int finished_in)
+{
+    // (a real call passes its arguments in vector registers: the pointer and the numbers are made scalar again)
+    const kernarg_ptr<EncodeArgs> ap = CIMG_OWN_KERNARGS(EncodeArgs, ap_in);
+    const int item = uni(item_in), last = uni(last_in), chunk = uni(chunk_in), finished = uni(finished_in);
+    uint32_t* cnt;
+    int nstreams;
+    {
+        const auto a = fresh(ap);
+        if (!uni(a->descs[chunk].assemble)) return last;
+        cnt = a->chunk_count + chunk;
+        nstreams = uni(a->descs[chunk].nstreams);
+        int32_t* nx = a->next_item + item;
+        FOR_LANES_W(l) { if (l == 0) *nx = last; }              // read back by this wave only
+    }
+    stores_performed();                                      // the records (written through) before the count says so
+    LV<uint32_t> got;
+    FOR_LANES(l) { got[l] = 0; }
+    FOR_LANES_W(l) { if (l == 0) got[l] = atomic_add_agent(cnt, (uint32_t)finished); }
+    const int before = uni((int)readlane(got, 0));
+    if (before + finished != nstreams) return item;
+    {
+        const AssembleArgs aa = assemble_args(ap);
+        LayoutChunk lc(aa, chunk);
+        const int64_t comp_off = uni64(aa.descs[chunk].comp_off);
+        lc.through = (((uintptr_t)aa.comp + (uintptr_t)comp_off) & 3) == 0;      // bstarts[] on a 4-byte boundary: written through
+        if (!lc.through) fence_acquire();                    // (else everybody's records are read past the L2: LayoutChunk::run)
+        lc.run();
+        FOR_LANES_W(l) { if (l == 0) atomic_store_agent(cnt, 0u); }  // the next batch counts from zero again
+        // header, bstarts, layout[chunk] before the flag says so: written through and acknowledged -- or, from an odd address,
+        // written back by an L2 flush
+        if (lc.through) stores_performed(); else fence_release();
+    }
+    const auto a = fresh(ap);
+    uint32_t* flag = a->ready + chunk;
+    const uint32_t gen = a->gen;
+    FOR_LANES_W(l) { if (l == 0) atomic_store_agent(flag, gen); }
+    debug_stamp(a->dbg, item, 1);                            // diagnostics (tools/diag_assemble.py): this item's wave closed a chunk
+    return item;
+}
+
+// The wave found the work queue empty: it copies the streams IT encoded into place, chunk by chunk as they become ready.  A chunk
+// that is not laid out yet is waited for (s_sleep + one atomic load per try; every chain that still encodes keeps its own SIMD
+// slot, so waiting waves hold nobody up) -- with a hard bound, after which the batch FAILS.
+CIMG_DEV_OUTLINE void encode_emit_own(kernarg_ptr<EncodeArgs> ap_in, int last_in)
+{
+    const kernarg_ptr<EncodeArgs> ap = CIMG_OWN_KERNARGS(EncodeArgs, ap_in);
+    const int last = uni(last_in);
+    const AssembleArgs aa = assemble_args(ap);
+    uint32_t* ready;
+    int32_t* next_item;
+    uint32_t gen;
+    int items, want_split, ts_arg;
+    {
+        const auto a = fresh(ap);
+        ready = a->ready; next_item = a->next_item; gen = a->gen; want_split = a->want_split; ts_arg = a->p.typesize;
+        items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0, a->block_items);
+    }
+    // Pass after pass over the wave's own items: an item whose chunk is laid out is copied into place and marked; the others are
+    // looked at again in the next pass (a nap in between).  Most of a wave's items belong to chunks that were finished long
+    // before it ran out of work; only the chunks that close at the very end of the launch are waited for.
+    enum : int { PASS_LIMIT = 1 << 20, ITEM_DONE = 1 << 30 };   // x (s_sleep + the polls of a pass) is seconds: only a lost chunk gets there
+    int known_ready = -1, known_not = -1;                    // per pass: the chunks last seen ready / not ready (a wave's items share chunks)
+    bool pending = true;
+    for (int pass = 0; pass < PASS_LIMIT && pending; ++pass) {
+        pending = false;
+        known_not = -1;
+        int it = last;
+        for (int n = 0; n <= items && it >= 0; ++n) {        // bounded: a wave cannot own more than every item
+            LV<int32_t> nx;
+            FOR_LANES(l) { nx[l] = next_item[it]; }
+            const int link = uni(readlane(nx, 0));
+            const bool marked = link >= 0 && (link & ITEM_DONE) != 0;                   // (the end of the list, -1, is not a mark: marks are non-negative)
+            const int next = marked ? (link & ~ITEM_DONE) - 1 : link;                   // a marked link holds (next + 1) | ITEM_DONE
+            if (!marked) {
+                int b, s;
+                encode_item_place(fresh(ap), it, b, s);
+                const int chunk = find_chunk(aa.descs, aa.nchunks, b, aa.uniform_nblocks);
+                bool is_ready = chunk == known_ready;
+                if (!is_ready && chunk != known_not) {
+                    LV<uint32_t> got;
+                    FOR_LANES(l) { got[l] = 0; }
+                    FOR_LANES_W(l) { if (l == 0) got[l] = atomic_load_agent(ready + chunk); }
+                    is_ready = uni(readlane(got, 0)) == gen;
+                    if (is_ready) known_ready = chunk;               // (what the closer and other waves wrote is read past the L2: EmitBlock::run_streams)
+                    else known_not = chunk;
+                }
+                if (is_ready) {
+                    const ChunkDesc d = uniform_desc(aa.descs + chunk);
+                    const int j = b - d.blk0;
+                    const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
+                    const int ns = (d.split && !leftover_blk) ? ts_arg : 1;
+                    const bool whole = ns > 1 && want_split && it < fresh(ap)->block_items;
+                    EmitBlock eb(aa, b);
+                    if (whole || ns == 1) eb.run_streams(0, ns);
+                    else eb.run_streams(s, s + 1);
+                    FOR_LANES_W(l) { if (l == 0) next_item[it] = (next + 1) | ITEM_DONE; }
+                    debug_stamp(fresh(ap)->dbg, it, 2);                 // diagnostics: the item's streams are in place
+                } else {
+                    pending = true;
+                }
+            }
+            it = next;
+        }
+        if (pending) wave_nap();
+    }
+    if (pending) { FOR_LANES_W(l) { if (l == 0 && aa.layout_host) aa.layout_host[aa.nchunks].cbytes = -1; } }
+}
+
 // one single-wave workgroup = one stream.  CODEC selects the stream codec at compile time: the two encoders live in
 // two kernels (merged into one, the scalar state of both pushed the LZ4 kernel from 38 to 84 spilled SGPRs)
 template <int CODEC>
@@ -1058,38 +1217,33 @@ struct EncodeStream {
         }
     }
 
-    // persistent workgroup: pull items until the queue is dry
+    // persistent workgroup: pull items until the queue is dry (EVERY wave pops exactly one item past the end: the host counts on
+    // that when it moves queue_base on), then -- when the batch is assembled in place -- copy blocks of finished chunks
     CIMG_DEV void run()
     {
-        int items;
+        int items, assemble;
         uint32_t* queue;
+        uint32_t qbase;
         {
             const auto a = fresh(ap);
             items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0, a->block_items);
             queue = a->queue;
+            qbase = a->queue_base;
+            assemble = a->assemble;
         }
         // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
+        int last = -1;                                           // the items this wave encoded, newest first (next_item[])
         for (int pops = 0; pops <= items; ++pops) {
             LV<uint32_t> got;
             FOR_LANES(l) { got[l] = 0; }
             FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(queue); }
-            const int item = uni((int)readlane(got, 0));
-            if (item >= items) return;
-            run_item(item);
+            const int item = uni((int)(readlane(got, 0) - qbase));
+            if (item >= items || item < 0) break;
+            int chunk = 0;
+            const int finished = run_item(item, chunk);
+            if (assemble && finished > 0) last = encode_account(ap, item, last, chunk, finished);
         }
-    }
-
-    // block and stream of a work item (encode_items)
-    CIMG_DEV static void item_place(kernarg_ptr<EncodeArgs> a, int item, int& b, int& s)
-    {
-        const int whole = a->want_split ? a->block_items : a->total_blocks;
-        if (item < whole) {
-            b = item; s = 0;
-        } else {
-            const int rest = a->total_blocks - whole, idx = item - whole;
-            b = whole + idx % rest;
-            s = a->p.streams_per_block - 1 - idx / rest;
-        }
+        if (assemble && last >= 0) encode_emit_own(ap, last);
     }
 
     // run check + codec on the stream that sits in LDS; leaves payload in the scratch slot and the record in recs
@@ -1114,11 +1268,19 @@ struct EncodeStream {
             }
         }
         // the record: its address is worked out again from the arguments (nothing of it was kept alive across the codec loop)
+        // (written THROUGH to memory, agent scope: the wave that lays the chunk out may sit on another XCD, whose L2 is not this one)
         StreamRec* dst = fresh(ap)->recs + rec_index;
-        FOR_LANES(l) { if (l == 0) *dst = r; }
+        FOR_LANES_W(l) {
+            if (l == 0) {
+                uint32_t* w = reinterpret_cast<uint32_t*>(dst);
+                atomic_store_agent(w + 0, (uint32_t)r.kind); atomic_store_agent(w + 1, (uint32_t)r.value);
+                atomic_store_agent(w + 2, (uint32_t)r.csize); atomic_store_agent(w + 3, (uint32_t)r.need);
+            }
+        }
     }
 
-    CIMG_DEV void run_item(int item)
+    // returns the number of streams this item finished (0: not an item of this launch) and their chunk
+    CIMG_DEV int run_item(int item, int& chunk_out)
     {
         // ---- stage the stream: everything read from the arguments here is dead before the codec loop starts ----------
         int neblock, accel_or_level, rec_index, planes = 1, ts = 1;
@@ -1128,17 +1290,18 @@ struct EncodeStream {
         {
             const auto a = fresh(ap);
             int b, s;
-            item_place(a, item, b, s);
-            if (b >= a->total_blocks) return;
+            encode_item_place(a, item, b, s);
+            if (b >= a->total_blocks) return 0;
             const int chunk = find_chunk(a->descs, a->nchunks, b, a->uniform_nblocks);
+            chunk_out = chunk;
             const ChunkDesc d = uniform_desc(a->descs + chunk);
-            if (d.memcpyed) return;
+            if (d.memcpyed) return 0;
             const int j = b - d.blk0;
             ts = a->p.typesize;
             const bool leftover_blk = (j == d.nblocks - 1 && d.leftover);
             const int bsize = leftover_blk ? d.leftover : d.blocksize;
             const int ns = (d.split && !leftover_blk) ? ts : 1;
-            if ((ns > 1) != (a->want_split != 0) || s >= ns) return;
+            if ((ns > 1) != (a->want_split != 0) || s >= ns) return 0;
             neblock = bsize / ns;
             const uint8_t* src = a->raw + d.raw_off + (int64_t)j * d.blocksize;
             const int filter = a->p.filter;
@@ -1176,6 +1339,7 @@ struct EncodeStream {
 #if !defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
         debug_stamp(dbg, item, 3);                                       // item done
 #endif
+        return planes;
     }
 };
 

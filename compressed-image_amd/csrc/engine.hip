@@ -153,7 +153,16 @@ struct cimg_engine {
     // one batch at a time per engine: the calls share the stream, the staging buffers and the result area.
     // (recursive: the host-buffer calls run the device calls inside)
     std::recursive_mutex mu;
-    bool queue_clean = false;           // both work-queue heads are zero (the layout kernel resets them)
+    // The encode launch's work-queue heads count on from batch to batch; the host keeps the value each starts a launch at.
+    // `sync` holds: words 0 / 4 the queue heads of the split / unsplit launch, then per chunk the count of finished streams, then
+    // per chunk the generation at which the chunk was last laid out inside a launch.  Zeroed when it is (re)allocated, when a
+    // counter nears wrap-around and after any failed batch (sync_dirty).
+    DevBuf sync, next_item;
+    uint32_t qbase[2] = {0, 0}, fold_gen = 0;
+    bool sync_dirty = true;
+    size_t sync_chunks = 0;             // chunks the current layout of `sync` was made for
+    bool no_fold = getenv("CIMG_NO_ASSEMBLE_IN_LAUNCH") != nullptr;   // diagnostic: cimg_layout_chunks / cimg_emit_blocks behind every encode launch
+    int64_t fold_batches = 0;
     // decode: the lean kernel (decode_lean_kernel.h) runs in front of the general one while it pays off
     DevBuf done;                        // uint32 per block: generation stamp of the lean kernel
     int lean_wgs_cu = 0, lean_wgs_lds = -1;   // resident lean decode waves per CU for that much LDS (occupancy query, cached)
@@ -393,7 +402,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_descs_dec, &e->h_out, &e->h_dec})
         if (b->p) (void)hipHostFree(b->p);
@@ -507,21 +516,35 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     int rc = plan_encode_batch(to_host(p), nchunks, raw_off, nbytes, comp_off, destsize, &plan);
     if (rc < 0) return e->fail(rc, "compress batch rejected by the planner (code %d): codec %d / filter pipeline / block size %d not available on the GPU path",
                                rc, p->compcode, p->blocksize);
-    const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
-    if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, e->h_descs, plan.descs.data(), desc_bytes))) return rc;
     if ((rc = e->reserve(e->recs, sizeof(StreamRec) * (size_t)plan.total_blocks * plan.cp.streams_per_block))) return rc;
     if ((rc = e->reserve(e->layout, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
-    if ((rc = e->reserve(e->h_out, sizeof(ChunkLayout) * (size_t)nchunks))) return rc;
+    if ((rc = e->reserve(e->h_out, sizeof(ChunkLayout) * ((size_t)nchunks + 1)))) return rc;
     if ((rc = e->reserve(e->scratch, (size_t)plan.total_blocks * plan.cp.slot_bytes + 64))) return rc;
     ChunkLayout* lay_host = nullptr;
     if ((rc = e->device_alias(e->h_out, &lay_host))) return rc;
-    if (!e->queue.p) e->queue_clean = false;
-    if ((rc = e->reserve(e->queue, 64))) return rc;
-    if (!e->queue_clean) {
-        if ((rc = e->hip(hipMemsetAsync(e->queue.p, 0, 64, e->stream), "queue memset"))) return rc;
+    // Chunks whose streams all belong to one encode launch are assembled INSIDE that launch (encode_kernel.h: ChunkDesc::assemble,
+    // set by the planner); the two assembly kernels run behind the launches only when a chunk is left for them (memcpyed up front,
+    // or full blocks split into planes plus an unsplit leftover block).
+    const bool fold = !e->no_fold;
+    bool leftovers = false;                         // some chunk is NOT assembled in a launch
+    if (!fold) for (ChunkDesc& d : plan.descs) d.assemble = 0;
+    for (const ChunkDesc& d : plan.descs) if (!d.assemble) leftovers = true;
+    const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
+    if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, e->h_descs, plan.descs.data(), desc_bytes))) return rc;
+    const size_t sync_words = 16 + 2 * (size_t)nchunks;
+    if (sync_words * 4 > e->sync.cap || (size_t)nchunks > e->sync_chunks) e->sync_dirty = true;
+    if ((rc = e->reserve(e->sync, sync_words * 4))) return rc;
+    for (int k = 0; k < 2; k++) if (e->qbase[k] > 0x70000000u) e->sync_dirty = true;
+    if (++e->fold_gen == 0) { e->fold_gen = 1; e->sync_dirty = true; }
+    if (e->sync_dirty) {
+        if ((rc = e->hip(hipMemsetAsync(e->sync.p, 0, e->sync.cap, e->stream), "sync memset"))) return rc;
+        e->qbase[0] = e->qbase[1] = 0;
+        e->sync_chunks = (e->sync.cap / 4 - 16) / 2;
+        e->sync_dirty = false;
     }
-    e->queue_clean = false;
+    ((ChunkLayout*)e->h_out.p)[nchunks].cbytes = 0;   // turns negative when a wave gave up waiting for a chunk (compress_finish)
     e->claunched = true;                          // from here on kernels may be in flight and h_out is this batch's
+    e->sync_dirty = true;                         // until the launches below are all enqueued: an error in between leaves the counters unknown
 
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
@@ -553,9 +576,14 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             dbg = (uint64_t*)e->dbg.p;
             e->dbg_count[0] = items;
         }
-        uint32_t* head = (uint32_t*)e->queue.p + (split ? 0 : 4);
+        uint32_t* const sync = (uint32_t*)e->sync.p;
+        uint32_t* head = sync + (split ? 0 : 4);
+        const size_t nslots = e->sync_chunks;
+        if ((rc = e->reserve(e->next_item, sizeof(int32_t) * (size_t)items + 64))) return rc;
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
-                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks};
+                      (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks,
+                      e->qbase[split], fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
+                      sync + 16, sync + 16 + nslots, (int32_t*)e->next_item.p, e->fold_gen};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : cimg_encode_streams;
         // persistent chains, as many as are resident at once and never more than there are items; ganged into workgroups so
@@ -591,13 +619,16 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
                     lds_bytes, gang, per_cu_use, gang * per_cu_use, e->num_cus, grid);
         }
         if ((rc = e->launch(CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes))) return rc;
+        // every wave of the launch pops exactly one item past the end
+        e->qbase[split] += (uint32_t)items + (uint32_t)grid * (uint32_t)gang;
     }
-    AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
-                    (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks,
-                    lay_host, (uint32_t*)e->queue.p};
-    if ((rc = e->launch(CIMG_K_LAYOUT, cimg_layout_chunks, aa, nchunks, 64, 0))) return rc;
-    e->queue_clean = true;                        // chunk 0's layout wave zeroes both queue heads for the next batch
-    if ((rc = e->launch(CIMG_K_EMIT, cimg_emit_blocks, aa, plan.total_blocks, 256, 0))) return rc;
+    if (leftovers) {
+        AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
+                        (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks, lay_host, 1};
+        if ((rc = e->launch(CIMG_K_LAYOUT, cimg_layout_chunks, aa, nchunks, 64, 0))) return rc;
+        if ((rc = e->launch(CIMG_K_EMIT, cimg_emit_blocks, aa, plan.total_blocks, 256, 0))) return rc;
+    }
+    e->sync_dirty = false;                        // everything enqueued: the counters end where the bases say
     return 0;
 }
 
@@ -607,6 +638,10 @@ static int compress_finish(cimg_engine* e, int32_t nchunks, int32_t* cbytes)
     if ((rc = cimg_engine_synchronize(e))) return rc;
     if (!e->claunched) return 0;                  // the batch was rejected before anything ran: there are no sizes to read
     const ChunkLayout* lay = (const ChunkLayout*)e->h_out.p;
+    if (lay[nchunks].cbytes < 0) {                // a wave of the encode launch waited in vain for a chunk to be laid out
+        e->sync_dirty = true;
+        return e->fail(ERR_FAILURE, "encode launch: a chunk was never published for assembly (in-launch hand-over timed out)");
+    }
     for (int i = 0; i < nchunks; i++) cbytes[i] = lay[i].cbytes;
     return 0;
 }

@@ -144,6 +144,8 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
         if (d.blocksize > cp.max_blocksize) cp.max_blocksize = d.blocksize;
         if (d.split && filter == FILTER_BITSHUFFLE) return ERR_CODEC_SUPPORT;   // bit rows are one stream (forced split: not built)
         if (d.split) cp.streams_per_block = cp.typesize;
+        // every stream of the chunk in ONE encode launch (full blocks split into planes AND an unsplit leftover block: two launches)
+        d.assemble = (!d.memcpyed && !(d.split && cp.typesize > 1 && d.leftover)) ? 1 : 0;
         if (!d.memcpyed) {
             const int nfull = d.leftover ? d.nblocks - 1 : d.nblocks;
             const bool multi = d.split && cp.typesize > 1;        // full blocks are cut into several planes

@@ -30,6 +30,7 @@
 #define CIMG_HD inline
 #define CIMG_UNROLL
 #define CIMG_DEV_NOINLINE inline
+#define CIMG_DEV_OUTLINE inline
 // the workgroup's LDS: in the emulator it is whatever buffer the harness passed in
 #define CIMG_LDS_BASE(passed) (passed)
 typedef uint8_t* cimg_global_u8p;
@@ -37,6 +38,7 @@ typedef uint8_t* cimg_global_u8p;
 // kernel arguments: a plain pointer in the emulator (see the device build)
 template <class T> using kernarg_ptr = const T*;
 template <class T> inline kernarg_ptr<T> fresh(kernarg_ptr<T> p) { return p; }
+#define CIMG_OWN_KERNARGS(T, passed) (passed)
 typedef volatile uint16_t* cimg_lds_vu16p;
 #define CIMG_AS_LDS_VU16(p) (reinterpret_cast<volatile uint16_t*>(p))
 
@@ -98,6 +100,14 @@ template <class T> inline void lane_scatter(const LV<T>& x, const LV<int>& idx, 
 // number of set bits of mask below lane l
 inline int lane_rank(uint64_t mask, int l) { return __builtin_popcountll(mask & ((1ull << l) - 1)); }
 inline uint32_t queue_pop(uint32_t* head) { return (*head)++; }
+// cross-workgroup hand-over inside a launch (encode_kernel.h: chunks assembled by the waves that encoded them): plain memory here
+inline void fence_release() {}
+inline void fence_acquire() {}
+inline uint32_t atomic_add_agent(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+inline uint32_t atomic_load_agent(const uint32_t* p) { return *p; }
+inline void atomic_store_agent(uint32_t* p, uint32_t v) { *p = v; }
+inline void wave_nap() {}
+inline void stores_performed() {}
 inline void atomic_count(uint32_t* p) { ++*p; }
 // value held by lane l-1 (lane 0 keeps its own)
 template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
@@ -118,6 +128,7 @@ template <class T> inline void lane_prev(const LV<T>& x, LV<T>& out)
 #define CIMG_UNROLL _Pragma("unroll")
 #define CIMG_HD __host__ __device__ __forceinline__
 #define CIMG_DEV_NOINLINE __device__ __forceinline__   /* out-of-line was measured 10 % slower (call + flat pointers) */
+#define CIMG_DEV_OUTLINE __device__ __attribute__((noinline))   /* really out of line: code that runs once per work item, no LDS access */
 // the workgroup's LDS is always reached through the ONE pointer the kernel derives from its
 // `extern __shared__` array: a second extern symbol would physically alias it while the compiler treats
 // two globals as distinct objects and may reorder accesses between them
@@ -132,6 +143,16 @@ typedef __attribute__((address_space(1))) uint8_t* cimg_global_u8p;
 template <class T> using kernarg_ptr = const T __attribute__((address_space(4)))*;
 template <class T> __device__ __forceinline__ kernarg_ptr<T> fresh(kernarg_ptr<T> p) { asm volatile("" : "+s"(p)); return p; }
 template <class T> __device__ __forceinline__ kernarg_ptr<T> kernel_args() { return (kernarg_ptr<T>)__builtin_amdgcn_kernarg_segment_ptr(); }
+// inside an out-of-line device function the pointer arrives in vector registers (the calling convention): both halves through
+// v_readfirstlane make it a scalar pointer into the kernel-argument segment again.  (__builtin_amdgcn_kernarg_segment_ptr() is
+// NOT usable there: in a callee it came back null on gfx950 / ROCm 7.2 and the first s_load faulted.)
+template <class T> __device__ __forceinline__ kernarg_ptr<T> kernarg_scalar_again(kernarg_ptr<T> p)
+{
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (kernarg_ptr<T>)(((uint64_t)hi << 32) | lo);
+}
+#define CIMG_OWN_KERNARGS(T, passed) (::kernarg_scalar_again<T>(passed))
 // volatile accesses are skipped by the compiler's address-space inference and would become FLAT ops
 // (slow, and not ordered with ds_* ops): LDS pointers that must be volatile carry the address space explicitly
 typedef volatile __attribute__((address_space(3))) uint16_t* cimg_lds_vu16p;
@@ -207,6 +228,26 @@ CIMG_DEV int lane_rank(uint64_t mask, int)
 }
 // one returning device-scope atomic on the queue head (MI355X_MICROARCH.md: 'dequeue', ~0.3-1.1 us)
 CIMG_DEV uint32_t queue_pop(uint32_t* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Cross-workgroup hand-over INSIDE a launch (encode_kernel.h: a chunk is laid out and copied into place by the waves of the launch
+// that encoded it).  Producer: plain stores, fence_release() by the whole wave, then a relaxed agent-scope atomic by one lane;
+// consumer: relaxed agent-scope atomic by one lane, then fence_acquire() by the whole wave, then plain loads.  On gfx950 the two
+// fences are what writes the producer's L2 back / drops the consumer's stale lines when the two sit on different XCDs.
+#ifdef CIMG_EXP_WG_FENCE     /* timing experiment only: no L2 write-back / invalidate -> results may be stale */
+CIMG_DEV void fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+CIMG_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#else
+CIMG_DEV void fence_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+CIMG_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+#endif
+CIMG_DEV uint32_t atomic_add_agent(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CIMG_DEV uint32_t atomic_load_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CIMG_DEV void atomic_store_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every store this wave issued so far is acknowledged (write-through stores: at the memory side)
+CIMG_DEV void stores_performed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifndef CIMG_NAP_REPEAT
+#define CIMG_NAP_REPEAT 1
+#endif
+CIMG_DEV void wave_nap() { _Pragma("unroll") for (int i = 0; i < CIMG_NAP_REPEAT; ++i) __builtin_amdgcn_s_sleep(127); }
 // a statistics counter that may live in page-locked host memory (system scope)
 CIMG_DEV void atomic_count(uint32_t* p) { (void)__hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // Clock reads for diagnostics.  s_memtime / s_memrealtime are SMEM ops: they count on lgkmcnt together

@@ -42,6 +42,11 @@ static HostCParams to_host(const EmuCParams* p)
     return h;
 }
 
+int g_emu_fold = 1;            // 0: the two assembly kernels behind the encode launches even where the launch could assemble
+int g_emu_folded = 0;          // chunks of the last batch that were assembled inside an encode launch
+extern "C" void emu_set_fold(int on) { g_emu_fold = on; }
+extern "C" int emu_last_folded(void) { return g_emu_folded; }
+
 int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, const int64_t* raw_off,
                        const int32_t* nbytes, uint8_t* comp, const int64_t* comp_off, const int32_t* destsize,
                        int32_t* cbytes)
@@ -51,28 +56,45 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     if (rc < 0) return rc;
     std::vector<uint8_t> scratch((size_t)plan.total_blocks * plan.cp.slot_bytes + 64, 0xEE);
     std::vector<StreamRec> recs((size_t)plan.total_blocks * plan.cp.streams_per_block);
-    std::vector<ChunkLayout> layout((size_t)nchunks);
+    std::vector<ChunkLayout> layout((size_t)nchunks), layout_host((size_t)nchunks + 1);
+    // as the engine does (engine.hip: compress_launch): chunks whose streams all belong to one launch are assembled inside it,
+    // the two assembly kernels run behind the launches for the others
+    const bool fold = g_emu_fold != 0;
+    bool leftovers = false;
+    if (!fold) for (ChunkDesc& d : plan.descs) d.assemble = 0;
+    int folded = 0;
+    for (const ChunkDesc& d : plan.descs) { if (!d.assemble) leftovers = true; else folded++; }
+    std::vector<uint32_t> chunk_count((size_t)nchunks, 0), ready((size_t)nchunks, 3);
+    const uint32_t gen = 5, qbase = 4294967000u;               // a queue head that counts on from earlier batches (and wraps in this one)
+    g_emu_folded = folded;
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;
         std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK);
-        uint32_t queue = 0;
+        uint32_t queue = qbase;
         bool block_items = split && g_emu_block_items;
         if (block_items)
             for (const ChunkDesc& d : plan.descs)
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
         // 1: every block whole; 2: the first half whole, the rest plane by plane (the mixed queue of a small batch)
         const int whole_blocks = !block_items ? 0 : (g_emu_block_items == 2 ? plan.total_blocks / 2 : plan.total_blocks);
-        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, whole_blocks};
+        std::vector<int32_t> next_item((size_t)encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks) + 1, -7);
+        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, whole_blocks,
+                      qbase, fold ? 1 : 0, comp, layout.data(), layout_host.data(), chunk_count.data(), ready.data(), next_item.data(), gen};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
             else { EncodeStream<CODEC_LZ4> es(&ea, lds.data(), w); es.run(); }
         }
     }
-    AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks, nullptr, nullptr};
-    for (int c = 0; c < nchunks; c++) { LayoutChunk lc(aa, c); lc.run(); }
-    for (int b = 0; b < plan.total_blocks; b++) { EmitBlock eb(aa, b); for (int w = 0; w < 4; w++) eb.run(w); }
+    if (layout_host[(size_t)nchunks].cbytes < 0) return -1;                      // a wave waited in vain
+    for (int c = 0; c < nchunks; c++) if (chunk_count[(size_t)c] != 0) return -1;   // every closer puts its count back to zero
+    for (int c = 0; c < nchunks; c++) if (plan.descs[(size_t)c].assemble && ready[(size_t)c] != gen) return -1;
+    if (leftovers) {
+        AssembleArgs aa{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), comp, layout.data(), plan.uniform_nblocks, nullptr, 1};
+        for (int c = 0; c < nchunks; c++) { LayoutChunk lc(aa, c); lc.run(); }
+        for (int b = 0; b < plan.total_blocks; b++) { EmitBlock eb(aa, b); for (int w = 0; w < 4; w++) eb.run(w); }
+    }
     for (int c = 0; c < nchunks; c++) cbytes[c] = layout[(size_t)c].cbytes;
     return 0;
 }

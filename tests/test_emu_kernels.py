@@ -303,3 +303,39 @@ def test_own_codec_with_an_unreadable_filter_is_an_error_not_a_zstd_retry():
     bad[2] = (bad[2] & 0x1F) | (3 << 5)                                # codec format 3 (zlib): nobody reads it
     rc, status, outs = E.decompress_batch([bytes(bad)], [raw.size], [32768])
     assert status == [-7]
+
+
+def test_chunks_assembled_inside_the_encode_launch_equal_the_two_kernel_path():
+    """Round 3: chunks whose streams all belong to ONE encode launch are laid out and copied into place by the waves of that
+    launch (encode_kernel.h: encode_account / encode_emit_own); the others -- memcpyed up front, or split planes plus an unsplit
+    leftover block -- by cimg_layout_chunks / cimg_emit_blocks behind it.  Both give the oracle's bytes (every other test of this
+    file runs the in-launch form where it applies); here the forms are compared on a batch that mixes all kinds of chunk, and the
+    harness's own checks (every closer puts its stream count back to zero, every assembled chunk is marked ready, the queue head
+    wraps around 2^32) run with it."""
+    L = E.lib()
+    L.emu_last_folded.restype = E.C.c_int
+    a = synth.tiled_channel(np.float16, 1024, 200)                       # 400 KiB
+    raw = a.view(np.uint8).ravel()
+    cases = [
+        ([131072] * 3 + [raw.size - 3 * 131072], 131072 + 32, 4, 4),     # three full chunks + a remainder chunk that is one (split) block
+        ([100000] * 4, 100000 + 32, 0, 4),                               # every chunk has a leftover block: split planes + one unsplit stream
+        ([131072, 20, 131072], 131072 + 32, 2, 3),                       # a 20-byte chunk in the middle: memcpyed up front
+    ]
+    for sizes, dest, want_folded, n in cases:
+        src = np.concatenate([raw[:s] for s in sizes])
+        got = {}
+        for fold in (1, 0):
+            L.emu_set_fold(fold)
+            try:
+                rc, cb, chunks = E.compress_batch(E.cparams(2), src, sizes, [dest] * len(sizes))
+            finally:
+                L.emu_set_fold(1)
+            assert rc == 0
+            assert L.emu_last_folded() == (want_folded if fold else 0), (sizes, fold, L.emu_last_folded())
+            got[fold] = chunks
+        assert got[0] == got[1]
+        off = 0
+        for c, s in zip(got[1], sizes):
+            r, want = O.compress(O.cparams(2), src[off:off + s], destsize=dest)
+            assert c == want
+            off += s

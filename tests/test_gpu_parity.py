@@ -342,6 +342,43 @@ def test_general_decode_kernel_alone_still_covers_every_block():
         e2.close()
 
 
+def test_assembly_inside_the_encode_launch_and_behind_it_give_the_same_chunks(eng):
+    """Round 3: chunks whose streams all belong to one encode launch are laid out and copied into place by the waves of that launch
+    (the wave that finishes a chunk's last stream lays it out; every wave copies the streams it encoded); memcpyed-up-front chunks
+    and chunks with split planes PLUS an unsplit leftover block go through cimg_layout_chunks / cimg_emit_blocks behind it.
+    CIMG_NO_ASSEMBLE_IN_LAUNCH=1 (read when an engine is created) sends everything the second way: same bytes, and both equal
+    the oracle's.  Run several times in a row: the queue heads and the per-chunk generation count on from batch to batch."""
+    os.environ["CIMG_NO_ASSEMBLE_IN_LAUNCH"] = "1"
+    try:
+        e2 = hip.Engine(0)
+    finally:
+        del os.environ["CIMG_NO_ASSEMBLE_IN_LAUNCH"]
+    try:
+        a = synth.tiled_channel(np.float16, 2048, 700)                       # 2.8 MB
+        raw = a.view(np.uint8).ravel()
+        for sizes, dest in (([262144] * 10 + [raw.size - 10 * 262144], 262144 + 32),      # whole blocks everywhere (last chunk: 245760 B... with a leftover?)
+                            ([100000] * 20, 100000 + 32),                                 # every chunk: split planes + an unsplit leftover block
+                            ([262144, 20, 262144, 31, 500000], 500000 + 32)):             # tiny chunks are memcpyed up front
+            src = np.concatenate([raw[:s] for s in sizes])
+            for rep in range(3):
+                got = eng.compress_host(hip.cparams(2), src, sizes, [dest] * len(sizes))
+                ref = e2.compress_host(hip.cparams(2), src, sizes, [dest] * len(sizes))
+                assert got == ref, (sizes[:3], rep)
+            off = 0
+            for c, n in zip(got, sizes):
+                assert c == O.compress(O.cparams(2), src[off:off + n], destsize=dest)[1]
+                off += n
+            outs, status = eng.decompress_host(got)
+            assert not status.any() and b"".join(o.tobytes() for o in outs) == src.tobytes()
+        # blosclz goes through the same launch shape
+        sizes = [131072] * 8
+        src = raw[:sum(sizes)]
+        got = eng.compress_host(hip.cparams(2, compcode=hip.BLOSCLZ), src, sizes, [131072 + 32] * 8)
+        assert got == e2.compress_host(hip.cparams(2, compcode=hip.BLOSCLZ), src, sizes, [131072 + 32] * 8)
+    finally:
+        e2.close()
+
+
 @pytest.mark.parametrize("force", ["1", "0"])
 def test_encode_block_items_and_plane_items_give_the_same_bytes(force):
     """The split encode launch hands out whole blocks (each read from HBM once, waiting planes in registers) on large

@@ -1,7 +1,11 @@
 #!/bin/bash
-# bench decode of several diagnostic builds: usage variants.sh <family> lib...
+# same-box A/B of differently built libraries (gpurun_in/<lib>, CIMG_LIB): usage variants.sh <family> lib...
 fam=$1; shift
 for lib in "$@"; do
-  CIMG_LIB=$PWD/gpurun_in/$lib python bench.py --no-cpu-baseline --steps 30 --family $fam 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels']; print('$lib', '$fam', 'enc', k['cimg_encode_streams']['avg_us'], 'dec', k['cimg_decode_blocks']['avg_us'], 'value', d['value'])"
+  CIMG_LIB=$PWD/gpurun_in/$lib timeout -k 10 200 python bench.py --no-cpu-baseline --steps 30 --family $fam 2>/dev/null | python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read()); k=d['kernels']; print('$lib', '$fam', 'enc', k['cimg_encode_streams']['avg_us'], 'layout+emit', k['cimg_layout_chunks']['avg_us'] + k['cimg_emit_blocks']['avg_us'], 'dec', k['cimg_decode_blocks']['avg_us'], 'ms/step', d['ms_per_step'], 'value', d['value'])
+except Exception as e:
+    print('$lib', '$fam', 'FAILED', e)"
 done
