@@ -36,6 +36,7 @@
 #include "wave.h"
 #include "decode_kernel.h"   // round16, find_chunk, byte_perm, wave copies
 #include "blosclz_kernel.h"
+#include "zstd_encode.h"      // the sequence sink of lz4_encode_body<true> and the frame around it (codec::zstd)
 #include "assemble_kernel.h"  // LayoutChunk / EmitBlock: run by the waves of the encode launch when the batch is assembled in place
 
 namespace cimg {
@@ -56,6 +57,10 @@ struct EncodeArgs {
     int32_t block_items;      // split launch only: the first `block_items` blocks are handed out WHOLE -- read from HBM once, the
                               // byte planes encoded one after the other by the same wave (the planes that wait sit in registers);
                               // the blocks behind them plane by plane
+    // codec::zstd (cimg_encode_streams_zstd): per-wave sequence records and the FSE tables of the predefined distributions
+    uint32_t* zstd_seq;       // wave w owns zstd_seq + w * zstd_seq_stride (dwords)
+    int32_t zstd_seq_stride;
+    const ZstdEncTables* zstd_tables;
     uint32_t queue_base;      // the queue head counts on from batch to batch: item = pop - queue_base (nothing resets it in between)
     // ---- chunks assembled INSIDE the launch (assemble != 0; round 3) ---------------------------------------------------------
     // A wave remembers the items it encoded (a linked list through next_item[]); the wave that finishes the last stream of a
@@ -337,7 +342,11 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
 // Bit-exact LZ4_compress_fast(in, out, n, cap, accel) in limited-output mode, byU16 table, by one wave.
 // in: LDS plane (8 readable bytes past the end), tab: 16 KiB LDS.  Returns bytes written, 0 if the
 // result does not fit cap.  need_out = smallest cap that still succeeds.
-CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* out_generic, int cap, int accel, int& need_out, uint64_t* dbg = nullptr, int item = 0)
+// SEQ = true (the zstd encoder, zstd_encode.h): the same search, but what it finds goes to `sink` as (literal length, offset, match
+// length) records, and `out` receives only the literal bytes -- cap then bounds those, and the return value is the number of
+// sequences (0: none, or the literals do not fit).
+template <bool SEQ = false>
+CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* out_generic, int cap, int accel, int& need_out, uint64_t* dbg = nullptr, int item = 0, SeqSink* sink = nullptr)
 {
     cimg_global_u8p out = CIMG_AS_GLOBAL(out_generic);
     CIMG_PROF_DECL;
@@ -529,7 +538,10 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     if (l == slot) { P_anchor[l] = anchor; P_lit[l] = lit; P_off[l] = ip - mp; P_mcode[l] = mcode; }
                 }
                 if (++np == 64) {
-                    if (!emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) return 2;
+                    bool fits_;
+                    if constexpr (SEQ) fits_ = zstd_take_parked(in, out, cap, op, *sink, np, P_anchor, P_lit, P_off, P_mcode);
+                    else fits_ = emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode);
+                    if (!fits_) return 2;
                     np = 0;
                 }
             }
@@ -790,6 +802,16 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
 #undef CIMG_SEQUENCE
 #undef CIMG_SEQUENCE_IN_HEAD
         if (ending <= 0) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return ending; }
+    }
+    if constexpr (SEQ) {
+        if (np && !zstd_take_parked(in, out, cap, op, *sink, np, P_anchor, P_lit, P_off, P_mcode)) return 0;
+        // the bytes behind the last match close the literal area
+        const int run = n - anchor;
+        if (op + run > cap) return 0;
+        emit_literals(in, anchor, out, op, run);
+        sink->lit_total = op + run;
+        need_out = 0;
+        return sink->nseq;
     }
     if (np && !emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode)) { CIMG_PROF_LAP(5); CIMG_PROF_STORE(dbg, item); return 0; }
     // ---- last literals ------------------------------------------------------------------------------------
@@ -1259,6 +1281,25 @@ struct EncodeStream {
             int need = 0;
             int cb;
             if constexpr (CODEC == CODEC_BLOSCLZ) cb = blosclz_encode_body(lds, lds + round16(neblock) + 16, neblock, out, neblock, accel_or_level, need);
+            else if constexpr (CODEC == CODEC_ZSTD) {
+                // one zstd frame (zstd_encode.h): the match finder's sequences go to this wave's record area, the literal bytes
+                // straight to their place in the frame, then the FSE-coded sequences section is built in LDS and appended
+                SeqSink sink;
+                const ZstdEncTables* tabs;
+                {
+                    const auto a = fresh(ap);
+                    sink.seq = a->zstd_seq + (size_t)w * (size_t)a->zstd_seq_stride;
+                    tabs = a->zstd_tables;
+                }
+                sink.nseq = 0; sink.lit_total = 0;
+                const int prefix = zstd_frame_prefix(neblock);
+                cb = 0;
+                if (neblock <= ZSTD_ENC_MAX_INPUT && prefix + 16 < neblock) {
+                    const int nseq = lz4_encode_body<true>(lds, lds + round16(neblock), neblock, out + prefix, neblock - prefix, 1, need, dbg, item, &sink);
+                    if (nseq > 0) cb = zstd_finish_frame(lds, round16(neblock), neblock, CIMG_AS_GLOBAL(out), neblock, sink, tabs);
+                }
+                need = cb;                                    // a frame fits a budget iff the budget holds its bytes
+            }
             else cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, accel_or_level, &need, dbg, item);
             if (cb > 0 && cb < neblock) {
                 r.kind = REC_LZ4; r.csize = cb; r.need = need;

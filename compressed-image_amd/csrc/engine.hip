@@ -55,6 +55,14 @@ extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode
     encode_gang<CODEC_BLOSCLZ>(lds);
 }
 
+// codec::zstd: the LZ4 match finder with a sequence sink + one zstd frame per stream (zstd_encode.h; format-valid, not byte-pinned)
+extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode_streams_zstd(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    (void)a;
+    encode_gang<CODEC_ZSTD>(lds);
+}
+
 // interleaved pixels -> planes, one wave per 16 KiB tile (deinterleave_kernel.h)
 extern "C" __global__ __launch_bounds__(64) void cimg_deinterleave(DeinterleaveArgs a)
 {
@@ -157,7 +165,7 @@ struct cimg_engine {
     // `sync` holds: words 0 / 4 the queue heads of the split / unsplit launch, then per chunk the count of finished streams, then
     // per chunk the generation at which the chunk was last laid out inside a launch.  Zeroed when it is (re)allocated, when a
     // counter nears wrap-around and after any failed batch (sync_dirty).
-    DevBuf sync, next_item;
+    DevBuf sync, next_item, zstd_seq, zstd_tables;   // (zstd encoder: per-wave sequence records, FSE tables of the predefined distributions)
     uint32_t qbase[2] = {0, 0}, fold_gen = 0;
     bool sync_dirty = true;
     size_t sync_chunks = 0;             // chunks the current layout of `sync` was made for
@@ -189,7 +197,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    int max_dyn_lds[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / (unused) / zstd
+    int max_dyn_lds[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd)
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -402,7 +410,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item, &e->zstd_seq, &e->zstd_tables})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_descs_dec, &e->h_out, &e->h_dec})
         if (b->p) (void)hipHostFree(b->p);
@@ -582,10 +590,12 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         if ((rc = e->reserve(e->next_item, sizeof(int32_t) * (size_t)items + 64))) return rc;
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks,
+                      nullptr, 0, nullptr,
                       e->qbase[split], fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
                       sync + 16, sync + 16 + nslots, (int32_t*)e->next_item.p, e->fold_gen};
-        const bool blz = plan.cp.compcode == CODEC_BLOSCLZ;
-        void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : cimg_encode_streams;
+        const bool blz = plan.cp.compcode == CODEC_BLOSCLZ, zst = plan.cp.compcode == CODEC_ZSTD;
+        void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : zst ? cimg_encode_streams_zstd : cimg_encode_streams;
+        const int lds_slot = blz ? 3 : zst ? 4 : 0;
         // persistent chains, as many as are resident at once and never more than there are items; ganged into workgroups so
         // that the 1280-byte LDS granules of a CU come out even (encode_gang above)
         if (e->enc_wgs_lds[split] != lds_bytes || e->enc_wgs_codec != plan.cp.compcode) {
@@ -608,8 +618,8 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         else if (items > wgs_for(1) * e->num_cus)                    // a small batch spreads single waves over the CUs
             for (int g = 2; g <= CIMG_ENC_GANG_MAX; ++g)
                 if (g * lds_bytes <= e->lds_per_wg && g * wgs_for(g) > gang * wgs_for(gang)) gang = g;
-        if (gang > 1 && e->allow_lds(enc_kernel, blz ? 3 : 0, gang * lds_bytes)) gang = 1;   // the runtime refused that much LDS for one workgroup
-        if ((rc = e->allow_lds(enc_kernel, blz ? 3 : 0, gang * lds_bytes))) return rc;
+        if (gang > 1 && e->allow_lds(enc_kernel, lds_slot, gang * lds_bytes)) gang = 1;   // the runtime refused that much LDS for one workgroup
+        if ((rc = e->allow_lds(enc_kernel, lds_slot, gang * lds_bytes))) return rc;
         int per_cu_use = std::max(wgs_for(gang), 1);
         if (e->enc_wgs_limit > 0) per_cu_use = std::max(1, std::min(per_cu_use, e->enc_wgs_limit));   // diagnostic: fewer resident workgroups
         const int grid = std::min((items + gang - 1) / gang, per_cu_use * e->num_cus);
@@ -618,7 +628,20 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             fprintf(stderr, "[cimg] encode launch: %d bytes LDS per chain, gangs of %d -> %d workgroup(s) per CU = %d chains per CU x %d CUs (grid %d)\n",
                     lds_bytes, gang, per_cu_use, gang * per_cu_use, e->num_cus, grid);
         }
-        if ((rc = e->launch(CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes))) return rc;
+        if (zst) {
+            // every wave of the launch owns room for the sequences of the largest stream (a sequence covers at least four bytes)
+            const int stride = 2 * (plan.cp.max_blocksize / 4 + 64);
+            if ((rc = e->reserve(e->zstd_seq, sizeof(uint32_t) * (size_t)stride * (size_t)grid * (size_t)gang))) return rc;
+            if (!e->zstd_tables.p) {
+                ZstdEncTables t;
+                zstd_build_enc_tables(&t);
+                if ((rc = e->reserve(e->zstd_tables, sizeof(t)))) return rc;
+                if ((rc = e->hip(hipMemcpyAsync(e->zstd_tables.p, &t, sizeof(t), hipMemcpyHostToDevice, e->stream), "zstd tables H2D"))) return rc;
+                if ((rc = e->hip(hipStreamSynchronize(e->stream), "zstd tables H2D"))) return rc;     // (t lives on this stack frame)
+            }
+            ea.zstd_seq = (uint32_t*)e->zstd_seq.p; ea.zstd_seq_stride = stride; ea.zstd_tables = (const ZstdEncTables*)e->zstd_tables.p;
+        }
+        if ((rc = e->launch(zst ? CIMG_K_ENCODE_ZSTD : CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes))) return rc;
         // every wave of the launch pops exactly one item past the end
         e->qbase[split] += (uint32_t)items + (uint32_t)grid * (uint32_t)gang;
     }

@@ -122,13 +122,16 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
     int filter = 0;
     int rc = single_filter(p, &filter);
     if (rc < 0) return rc;
-    if (p.compcode != CODEC_LZ4 && p.compcode != CODEC_BLOSCLZ) return ERR_CODEC_SUPPORT;   // lz4hc / zstd encoders: not on the GPU path (their chunks decode)
+    // lz4 and blosclz: bit-exact encoders.  lz4hc and zstd: FORMAT-VALID encoders whose bytes differ from liblz4's / libzstd's by
+    // construction: lz4hc chunks are LZ4 blocks from the fast match finder at acceleration 1, zstd chunks are
+    // frames built from the same matches (zstd_encode.h).  zlib: not built.
+    if (p.compcode != CODEC_LZ4 && p.compcode != CODEC_BLOSCLZ && p.compcode != CODEC_LZ4HC && p.compcode != CODEC_ZSTD) return ERR_CODEC_SUPPORT;
     CodecParams& cp = plan->cp;
     cp.typesize = p.typesize > 255 ? 1 : p.typesize;
     cp.clevel = p.clevel;
     cp.compcode = p.compcode;
     cp.filter = filter;
-    cp.accel = 10 - p.clevel;
+    cp.accel = (p.compcode == CODEC_LZ4HC || p.compcode == CODEC_ZSTD) ? 1 : 10 - p.clevel;   // (the substitutes always search at acceleration 1)
     cp.max_blocksize = 0;
     cp.streams_per_block = 1;
     int32_t blk = 0;
@@ -153,7 +156,7 @@ inline int plan_encode_batch(const HostCParams& p, int nchunks, const int64_t* r
             if (!multi && nfull > 0) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.blocksize, p.compcode));
             if (d.leftover) plan->lds_unsplit = imax(plan->lds_unsplit, encode_lds_bytes(d.leftover, p.compcode));
             const int stream_max = multi ? imax(nfull > 0 ? d.blocksize / cp.typesize : 0, d.leftover) : d.blocksize;
-            if (stream_max > (p.compcode == CODEC_BLOSCLZ ? BLZ_MAX_INPUT : LZ4_MAX_INPUT_U16)) return ERR_CODEC_SUPPORT;   // 32-bit position tables: not built
+            if (stream_max > (p.compcode == CODEC_BLOSCLZ ? (int)BLZ_MAX_INPUT : p.compcode == CODEC_ZSTD ? (int)ZSTD_ENC_MAX_INPUT : (int)LZ4_MAX_INPUT_U16)) return ERR_CODEC_SUPPORT;   // 32-bit position tables: not built
         }
     }
     if (plan->lds_split > MAX_LDS_BYTES || plan->lds_unsplit > MAX_LDS_BYTES) return ERR_CODEC_SUPPORT;

@@ -105,7 +105,7 @@ struct ZstdBack {
 
 // a byte every lane reads from the same address: wave-uniform, and said so (the decoder's control flow then stays scalar)
 CIMG_DEV int zstd_u8(const uint8_t* p, int i) { return (int)uni((uint32_t)p[i]); }
-CIMG_DEV int zstd_highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
+CIMG_HD int zstd_highbit(uint32_t v) { int r = -1; while (v) { v >>= 1; r++; } return r; }
 
 // ---- FSE ------------------------------------------------------------------------------------------------------------
 // table description at src[0..size): fills w->freq, returns bytes consumed (< 0: error); *log_out = accuracy log
@@ -178,7 +178,7 @@ CIMG_DEV int zstd_fse_build(ZstdFseEntry* t, int log, int nsym, ZstdWork* w)
 CIMG_DEV void zstd_fse_rle(ZstdFseEntry* t, int sym) { t[0].sym = (uint8_t)sym; t[0].nb = 0; t[0].base = 0; }
 
 // predefined distributions (RFC 8878 section 3.1.1.3.2.2)
-CIMG_DEV int zstd_default_freq(int which, int i)
+CIMG_HD int zstd_default_freq(int which, int i)
 {
     // which: 0 literal lengths (36 symbols, log 6), 1 offsets (29, log 5), 2 match lengths (53, log 6)
     if (which == 0) {

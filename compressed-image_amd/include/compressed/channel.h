@@ -154,19 +154,17 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		size_t m_Width = 1;
 		size_t m_Height = 1;
 
-		// `adopted`: the chunks exist already.  A table written elsewhere with a codec this path only READS (lz4hc, zstd) is
-		// adopted without a compression context: its chunks decode, anything that would re-encode one (set_chunk, the
-		// iterator) throws.  Everywhere else a decode-only codec fails here, where the choice is made.
+		// All four codecs of the reference have an encoder on this path since round 3 (lz4hc / zstd: format-valid, not the CPU
+		// libraries' bytes -- enums.h), so an adopted chunk table of any of them can be rewritten like one built from pixels.
 		void make_contexts(size_t block_size)
 		{
-			const bool read_only = m_Adopted && (m_Codec == enums::codec::lz4hc || m_Codec == enums::codec::zstd);
-			m_CompressionContext = read_only ? blosc2::context_ptr(nullptr) : blosc2::create_compression_context<T>(m_Nthreads, m_Codec, m_CompressionLevel, block_size);
+			m_CompressionContext = blosc2::create_compression_context<T>(m_Nthreads, m_Codec, m_CompressionLevel, block_size);
 			m_DecompressionContext = blosc2::create_decompression_context(m_Nthreads);
 		}
 		void require_encoder() const
 		{
 			if (!m_CompressionContext)
-				throw std::runtime_error("this channel's codec (lz4hc / zstd) is decode-only on the MI355X GPU path: its chunks can be read, not rewritten");
+				throw std::runtime_error("Internal Error: Channel instance has no compression context");
 		}
 		void require() const
 		{

@@ -10,8 +10,8 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 		{
 			blosclz,   // GPU encode + decode (bytes of BloscLZ 2.3.0, csrc/blosclz_kernel.h)
 			lz4,       // GPU encode + decode (the reference's default, channel.h:101)
-			lz4hc,     // decode only (codec format 1 = LZ4 blocks); compressing fails with BLOSC2_ERROR_CODEC_SUPPORT
-			zstd       // decode only (codec format 4, csrc/zstd_kernel.h: a slow path); compressing fails with BLOSC2_ERROR_CODEC_SUPPORT
+			lz4hc,     // codec format 1 (LZ4 blocks).  Written here by the FAST match finder at acceleration 1: valid for every LZ4 decoder, not LZ4_compress_HC's bytes
+			zstd       // codec format 4 (one zstd frame per stream).  Written by csrc/zstd_encode.h: valid for every zstd decoder, not libzstd's bytes; read by csrc/zstd_kernel.h
 		};
 	}
 }

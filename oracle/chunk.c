@@ -168,7 +168,11 @@ static int codec_compress(const orc_cparams* p, const uint8_t* s, int n, uint8_t
         if (need && r > 0) *need = r;
         return r;
     }
-    return ORC_ERR_CODEC_SUPPORT;          /* the lz4hc encoder is not restated (its chunks still decode) */
+    /* lz4hc: NOT LZ4_compress_HC.  The GPU path writes lz4hc chunks as LZ4 blocks from the fast match finder at acceleration 1
+     * (format-valid -- codec format 1, any LZ4 decoder reads them -- but not liblz4's HC bytes), and this
+     * is the checker's twin of THAT, so that the GPU's lz4hc chunks can be compared byte for byte with something. */
+    if (p->compcode == ORC_LZ4HC) return orc_lz4_compress_fast(s, n, d, maxout, 1, need);
+    return ORC_ERR_CODEC_SUPPORT;
 }
 
 /* one block, written at dst (= chunk + ntbytes).  Returns block bytes, 0 = does not fit, <0 error. */
@@ -285,7 +289,7 @@ int orc_blosc2_compress_2phase(const orc_cparams* p, const void* src_, int32_t n
     const int ts = p->typesize > MAX_TYPESIZE ? 1 : p->typesize;
     write_header(p, &g, nbytes, dst);
     if (g.memcpyed) return finish_memcpyed(&g, src, nbytes, dst, destsize);
-    if (p->compcode != ORC_LZ4 && p->compcode != ORC_BLOSCLZ && p->compcode != ORC_ZSTD) return ORC_ERR_CODEC_SUPPORT;
+    if (p->compcode != ORC_LZ4 && p->compcode != ORC_BLOSCLZ && p->compcode != ORC_ZSTD && p->compcode != ORC_LZ4HC) return ORC_ERR_CODEC_SUPPORT;
 
     const int maxstreams = g.split ? ts : 1;
     const size_t slot = (size_t)g.blocksize + 16;

@@ -52,7 +52,7 @@ typedef struct {
     int32_t clevel;      /* 0..9 */
     int32_t typesize;    /* sizeof(T) */
     int32_t blocksize;   /* requested block size in bytes (0 unsupported: the reference always sets it) */
-    int32_t compcode;    /* ORC_LZ4 or ORC_BLOSCLZ restated; ORC_ZSTD through the box's libzstd (zstd_dl.c); lz4hc: decode only */
+    int32_t compcode;    /* ORC_LZ4 / ORC_BLOSCLZ restated; ORC_ZSTD through the box's libzstd (zstd_dl.c); ORC_LZ4HC: the GPU path's substitute (LZ4 fast, acceleration 1), not LZ4_compress_HC */
     int32_t splitmode;   /* ORC_AUTO_SPLIT is what the reference uses (wrapper.h:328,353) */
     uint8_t filters[ORC_MAX_FILTERS];      /* default {0,0,0,0,0,ORC_SHUFFLE} */
     uint8_t filters_meta[ORC_MAX_FILTERS];

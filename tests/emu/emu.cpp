@@ -78,12 +78,18 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
         // 1: every block whole; 2: the first half whole, the rest plane by plane (the mixed queue of a small batch)
         const int whole_blocks = !block_items ? 0 : (g_emu_block_items == 2 ? plan.total_blocks / 2 : plan.total_blocks);
+        const int zstride = 2 * (plan.cp.max_blocksize / 4 + 64);
+        std::vector<uint32_t> zseq((size_t)zstride * 3, 0xA5A5A5A5u);
+        static ZstdEncTables ztabs;
+        zstd_build_enc_tables(&ztabs);
         std::vector<int32_t> next_item((size_t)encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks) + 1, -7);
         EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, whole_blocks,
+                      zseq.data(), zstride, &ztabs,
                       qbase, fold ? 1 : 0, comp, layout.data(), layout_host.data(), chunk_count.data(), ready.data(), next_item.data(), gen};
         for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
+            else if (plan.cp.compcode == CODEC_ZSTD) { EncodeStream<CODEC_ZSTD> es(&ea, lds.data(), w); es.run(); }
             else { EncodeStream<CODEC_LZ4> es(&ea, lds.data(), w); es.run(); }
         }
     }
@@ -184,6 +190,24 @@ int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, 
     const int r = lz4_encode_wave(lds.data(), 0, round16(n), n, dst, cap, accel, &nd);
     if (need) *need = nd;
     return r;
+}
+
+// one stream through the zstd ENCODER of csrc/zstd_encode.h (the LZ4 match finder with a sequence sink + the frame around it)
+int emu_zstd_encode(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    if (n > ZSTD_ENC_MAX_INPUT) return -1;
+    std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
+    memcpy(lds.data(), src, (size_t)n);
+    std::vector<uint32_t> seq((size_t)2 * (n / 4 + 64), 0xA5A5A5A5u);
+    static ZstdEncTables tabs;
+    zstd_build_enc_tables(&tabs);
+    SeqSink sink{seq.data(), 0, 0};
+    int need = 0;
+    const int prefix = zstd_frame_prefix(n);
+    if (prefix + 16 >= cap) return 0;
+    const int nseq = lz4_encode_body<true>(lds.data(), lds.data() + round16(n), n, dst + prefix, cap - prefix, 1, need, nullptr, 0, &sink);
+    if (nseq <= 0) return 0;
+    return zstd_finish_frame(lds.data(), round16(n), n, dst, cap, sink, &tabs);
 }
 
 // one zstd frame through csrc/zstd_decode.h (the work area the kernel keeps in LDS is on the heap here)

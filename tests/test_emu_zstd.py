@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import _emu as E
+from cimg import synth
 
 
 @pytest.fixture(scope="module")
@@ -143,3 +144,94 @@ def test_zstd_chunks_through_the_reference_entry_point_on_the_mock_library(kat):
             assert L.blosc2_decompress_ctx(d, c.ctypes.data, c.size, out.ctypes.data, out.size - 1) < 0
     finally:
         L.blosc2_free_ctx(d)
+
+
+def test_zstd_encoder_frames_decode_with_libzstd_and_with_the_own_decoder():
+    """csrc/zstd_encode.h on the host lane emulator: one stream -> one zstd frame (raw literals, predefined FSE tables, offsets never
+    as repeat codes).  FORMAT-VALID, NOT BYTE-PINNED: every frame must decode to its input with the box's libzstd (skipped where
+    there is none) AND with csrc/zstd_decode.h; a stream that does not shrink gives 0 (c-blosc2 then stores it raw).  Sizes land
+    between LZ4's and libzstd's."""
+    import ctypes as C
+    import _oracle as O
+    L = E.lib()
+    L.emu_zstd_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.emu_zstd_encode.restype = C.c_int
+    have = O.zstd_available()
+    OL = O.lib()
+    OL.orc_zstd_decompress_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    OL.orc_zstd_decompress_stream.restype = C.c_int
+    rng = np.random.default_rng(5)
+    plane = lambda a, ts, s: np.ascontiguousarray(a.view(np.uint8).reshape(-1, ts)[:, s])
+    cases = {
+        "tiled_hi": plane(synth.tiled_channel(np.float16, 4096, 4), 2, 1),
+        "tiled_lo_noise": plane(synth.tiled_channel(np.float16, 4096, 4), 2, 0),
+        "natural_hi": plane(synth.natural_channel(np.uint16, 4096, 4), 2, 1),
+        "natural_lo": plane(synth.natural_channel(np.uint16, 4096, 4), 2, 0),
+        "text": np.frombuffer((b"the quick brown fox jumps over the lazy dog, " * 400)[:16000], np.uint8),
+        "runs": np.concatenate([np.zeros(5000, np.uint8), rng.integers(0, 4, 3000, dtype=np.uint8), np.full(8000, 7, np.uint8)]),
+        "unsplit_32k_f32": synth.tiled_channel(np.float32, 4096, 2).view(np.uint8).ravel()[:32768],
+        "period_10": np.tile(np.arange(10, dtype=np.uint8), 20),
+        "far_matches_60k": np.tile(rng.integers(0, 256, 3000, dtype=np.uint8), 20)[:60000],
+        "max_65535": np.tile(rng.integers(0, 7, 257, dtype=np.uint8), 256)[:65535],
+        "one_long_literal_run_then_match": np.concatenate([rng.integers(0, 256, 20000, dtype=np.uint8), np.zeros(3000, np.uint8)]),
+        "tiny_40": np.zeros(40, np.uint8) + np.arange(40, dtype=np.uint8) % 3,
+        "random": rng.integers(0, 256, 16384, dtype=np.uint8),
+    }
+    for k in range(40):                                           # many sequences with long literal / match lengths of every code
+        n = int(rng.integers(64, 40000))
+        pieces, left = [], n
+        while left > 0:
+            m = int(min(left, rng.choice([1, 3, 15, 16, 40, 70, 130, 300, 2000])))
+            pieces.append(rng.integers(0, 256, m, dtype=np.uint8) if rng.random() < 0.5 else np.full(m, rng.integers(0, 256), np.uint8))
+            left -= m
+        cases["mix%d" % k] = np.concatenate(pieces)
+    coded = 0
+    for name, src in cases.items():
+        n = src.size
+        dst = np.full(n + 64, 0xEE, np.uint8)
+        r = L.emu_zstd_encode(src.ctypes.data, n, dst.ctypes.data, n)
+        assert 0 <= r < n, name
+        assert (dst[n:] == 0xEE).all(), name                      # nothing is written past the stream's budget
+        if r == 0:
+            continue
+        coded += 1
+        assert bytes(dst[:4]) == b"\x28\xb5\x2f\xfd"
+        r2, own = E.zstd_decode(dst[:r].tobytes(), n)
+        assert r2 == n and own == src.tobytes(), name
+        if have:
+            out = np.zeros(n, np.uint8)
+            assert OL.orc_zstd_decompress_stream(dst.ctypes.data, r, out.ctypes.data, n) == n, name
+            assert out.tobytes() == src.tobytes(), name
+    assert coded >= 40
+    assert L.emu_zstd_encode(cases["random"].ctypes.data, 16384, np.zeros(16500, np.uint8).ctypes.data, 16384) == 0   # noise: no frame
+
+
+def test_zstd_and_lz4hc_chunks_from_the_emulated_kernels():
+    """Whole chunks with codec::zstd / codec::lz4hc through the emulated encode kernels + in-launch assembly: the checker's chunk
+    layer (libzstd / the LZ4 block decoder) and the emulated decode kernels both return the pixels; lz4hc chunks equal the checker's
+    twin (LZ4 fast at acceleration 1 under compcode 2) byte for byte; zstd splits planes up to clevel 5 like c-blosc2."""
+    import _oracle as O
+    for codec in (O.ZSTD, O.LZ4HC):
+        for clevel in (9, 5, 1):
+            for dtype, arr in ((np.float16, synth.tiled_channel(np.float16, 1024, 100)), (np.uint16, synth.natural_channel(np.uint16, 512, 130)),
+                               (np.float32, synth.tiled_channel(np.float32, 512, 70)), (np.uint8, synth.natural_channel(np.uint8, 700, 99))):
+                it = np.dtype(dtype).itemsize
+                raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
+                chunk = 65536
+                sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
+                rc, cb, chunks = E.compress_batch(E.cparams(it, clevel=clevel, compcode=codec), raw, sizes, [chunk + 32] * len(sizes))
+                assert rc == 0
+                off = 0
+                for c, n in zip(chunks, sizes):
+                    assert c[22] == codec
+                    if codec == O.ZSTD and not O.zstd_available():
+                        off += n
+                        continue
+                    r, px = O.decompress(c)
+                    assert r == n and px.tobytes() == raw[off:off + n].tobytes(), (codec, clevel, np.dtype(dtype).name)
+                    if codec == O.LZ4HC:
+                        assert c == O.compress(O.cparams(it, clevel=clevel, compcode=O.LZ4HC), raw[off:off + n], destsize=chunk + 32)[1]
+                    off += n
+                rc, status, outs = E.decompress_batch(chunks, sizes, [O.cbuffer_sizes(c)[2] for c in chunks])
+                assert rc == 0 and not any(status)
+                assert b"".join(o.tobytes() for o in outs) == raw.tobytes()

@@ -117,11 +117,9 @@ def test_edge_geometries(eng):
 def test_empty_batch_and_unsupported_requests_fail_loudly(eng):
     assert eng.compress_device(hip.cparams(2), 0, [], [], 0, [], []).size == 0
     raw = synth.natural_channel(np.uint16, 256, 64)
-    with pytest.raises(hip.CodecError) as ei:
-        eng.compress_host(hip.cparams(2, compcode=hip.ZSTD), raw, [raw.nbytes], [raw.nbytes + 32])
+    with pytest.raises(hip.CodecError) as ei:                                 # zlib: the one blosc2 codec nobody here writes
+        eng.compress_host(hip.cparams(2, compcode=hip.ZLIB), raw, [raw.nbytes], [raw.nbytes + 32])
     assert ei.value.code == -7
-    with pytest.raises(hip.CodecError):                                       # lz4hc: decode only
-        eng.compress_host(hip.cparams(2, compcode=hip.LZ4HC), raw, [raw.nbytes], [raw.nbytes + 32])
     with pytest.raises(hip.CodecError):                                       # a second filter in the pipeline
         eng.compress_host(hip.cparams(2, filters=(0, 0, 0, 0, hip.SHUFFLE, hip.BITSHUFFLE)), raw, [raw.nbytes], [raw.nbytes + 32])
 
@@ -724,7 +722,7 @@ def test_truncated_chunk_buffer_is_refused_before_it_is_read(eng):
 
 def test_lz4hc_chunks_decode_on_the_gpu(eng, golden_dir):
     """enums::codec::lz4hc chunks (coded by liblz4's LZ4_compress_HC, tests/golden/make_lz4hc_golden.py) are codec
-    format 1: they decode through the ordinary kernels; compressing with lz4hc is refused (test above)."""
+    format 1: they decode through the ordinary kernels (what this engine writes under that name: test_zstd_and_lz4hc_encoders...)."""
     kat = np.load(os.path.join(golden_dir, "lz4hc_kat.npz"))
     chunks = [kat["chunk|" + str(n)].tobytes() for n in kat["cases"]]
     outs, status = eng.decompress_host(chunks)
@@ -736,7 +734,7 @@ def test_lz4hc_chunks_decode_on_the_gpu(eng, golden_dir):
 def test_zstd_chunks_decode_on_the_gpu(eng, golden_dir):
     """enums::codec::zstd chunks (streams = frames of the system libzstd, tests/golden/make_zstd_golden.py) are codec format 4:
     cimg_decode_blocks hands them to cimg_decode_zstd (csrc/zstd_kernel.h, the slow path).  Alone, and mixed into a batch with
-    LZ4 chunks; a damaged one fails by itself.  Compressing with zstd stays refused (test_empty_batch_and_unsupported...)."""
+    LZ4 chunks; a damaged one fails by itself.  (The engine's own zstd chunks: test_zstd_and_lz4hc_encoders_write_valid_chunks.)"""
     kat = np.load(os.path.join(golden_dir, "zstd_kat.npz"))
     names = [str(n) for n in kat["chunks"]]
     chunks = [kat["chunk|" + n].tobytes() for n in names]
@@ -875,3 +873,43 @@ def test_config5_zstd_full_size_one_rank_share(eng):
         assert (flags >> 5) == 4 and bool(flags & 0x10) == (clevel > 5)          # codec format 4; unsplit above clevel 5
         print(f"configs[4] share: {count} chunks at zstd clevel {clevel}: ratio {n / float(cb.sum()):.3f}")
         d_comp.free(); d_raw.free()
+
+
+def test_zstd_and_lz4hc_encoders_write_valid_chunks(eng):
+    """enums::codec::zstd / lz4hc (enums.h:18-24) construct and compress.  Their chunks are FORMAT-VALID, NOT BYTE-PINNED (DESIGN.md
+    section 2): zstd streams are frames built by csrc/zstd_encode.h (raw literals + predefined FSE tables over the wave's LZ4
+    matches), lz4hc streams are LZ4 blocks from the fast match finder.  Checked here: (1) the box's own libzstd (through the
+    checker's chunk layer) and liblz4's format twin decode every chunk to the pixels, (2) so do the GPU decoders, (3) the bytes
+    equal what the kernel sources produce on the host lane emulator, (4) headers say what c-blosc2 would say (compcode, codec
+    format, the split rule of the level), (5) lz4hc chunks equal the checker's twin byte for byte.  Ratios are printed."""
+    import _emu as Em
+    cases = []
+    for dtype, fam in ((np.float16, "tiled"), (np.uint16, "natural"), (np.float32, "tiled"), (np.uint8, "natural"), (np.uint16, "zero"), (np.uint16, "random")):
+        cases.append((dtype, getattr(synth, fam + "_channel")(dtype, 1024, 200), fam))
+    for codec, name in ((hip.ZSTD, "zstd"), (hip.LZ4HC, "lz4hc")):
+        for clevel in (9, 3):
+            for dtype, arr, fam in cases:
+                it = np.dtype(dtype).itemsize
+                raw = np.ascontiguousarray(arr).view(np.uint8).ravel()
+                chunk = 131072
+                sizes = [min(chunk, raw.size - o) for o in range(0, raw.size, chunk)]
+                got = eng.compress_host(hip.cparams(it, clevel=clevel, compcode=codec), raw, sizes, [chunk + 32] * len(sizes))
+                rc, cb, emu = Em.compress_batch(Em.cparams(it, clevel=clevel, compcode=codec), raw, sizes, [chunk + 32] * len(sizes))
+                assert rc == 0 and got == emu, (name, clevel, np.dtype(dtype).name, fam)
+                off = 0
+                for c, n in zip(got, sizes):
+                    assert 0 < len(c) <= n + 32
+                    assert c[22] == codec and (c[2] >> 5) == (4 if codec == hip.ZSTD else 1) or (c[2] & 0x02)      # (memcpyed chunks keep the bits too)
+                    if not (c[2] & 0x02) and it > 1:
+                        assert bool(c[2] & 0x10) == (not (codec == hip.ZSTD and clevel <= 5)), (name, clevel)      # zstd splits up to level 5, lz4hc never
+                    if codec == hip.ZSTD and not O.zstd_available():
+                        pass
+                    else:
+                        r, px = O.decompress(c)
+                        assert r == n and px.tobytes() == raw[off:off + n].tobytes(), (name, clevel, fam)
+                    if codec == hip.LZ4HC:
+                        assert c == O.compress(O.cparams(it, clevel=clevel, compcode=O.LZ4HC), raw[off:off + n], destsize=chunk + 32)[1]
+                    off += n
+                outs, status = eng.decompress_host(got)
+                assert not status.any() and b"".join(o.tobytes() for o in outs) == raw.tobytes(), (name, clevel, fam)
+                print(f"{name} clevel {clevel} {np.dtype(dtype).name} {fam}: ratio {raw.size / sum(map(len, got)):.3f}")
