@@ -18,7 +18,9 @@
 //
 // FSE coding walks the sequences from the last to the first (the decoder reads the bit stream backwards), one sequence at a
 // time, wave-uniform scalar code (like the decoder in zstd_decode.h: all lanes run it with the same data); the bit stream is
-// collected in LDS -- the plane is not needed any more once the match finder is done -- and copied out 16 bytes per lane.
+// collected in LDS, in the hash table's place behind the FSE tables (about 15 KiB: a stream with more sequence bits than that is
+// not worth a frame) -- NOT in the plane's: the plane is still needed when the frame turns out not to be smaller than its input
+// and the stream is stored raw.
 #pragma once
 #include "codec_types.h"
 #include "wave.h"
@@ -26,7 +28,8 @@
 
 namespace cimg {
 
-enum : int { ZSTD_ENC_MAX_INPUT = 65535 };       // literal lengths, match lengths and offsets of a stream fit 16 bits
+enum : int { ZSTD_ENC_MAX_INPUT = 65535,         // literal lengths, match lengths and offsets of a stream fit 16 bits
+              ZSTD_ENC_STAGE_END = 16384 - 16 };  // the bit stream is staged inside the 16 KiB of the (dead) hash table, behind the FSE tables
 
 // FSE compression tables of the three predefined distributions (literal lengths: 36 symbols, log 6; offsets: 29, log 5; match
 // lengths: 53, log 6), built once on the host the way FSE_buildCTable builds them: state table + per symbol (deltaNbBits,
@@ -203,10 +206,12 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
     const int nseq_bytes = nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
     const int stream_at = seq_at + nseq_bytes + 1;               // the FSE bit stream (behind the symbol-compression-modes byte)
     if (stream_at + 8 >= cap) return 0;
-    // the bit stream is collected in LDS, in the plane's place: at most cap - stream_at bytes are of any use
-    const int room = imin(cap - stream_at, imax(tab_off - 16, 0));
+    // the bit stream is collected in LDS behind the tables (the plane stays intact: a frame that does not pay is followed by a raw
+    // store of the plane); at most cap - stream_at bytes are of any use
+    const int stage = tab_off + (int)((sizeof(ZstdEncTables) + 15) & ~(size_t)15);
+    const int room = imin(cap - stream_at, tab_off + ZSTD_ENC_STAGE_END - stage);
     ZstdBitWriter bw;
-    bw.init(lds, 0, room);
+    bw.init(lds, stage, stage + room);
     // ---- FSE: the last sequence first ---------------------------------------------------------------------------------------
     uint32_t st_ll = 0, st_of = 0, st_ml = 0;
     for (int base = ((nseq - 1) >> 6) << 6; base >= 0; base -= 64) {          // batches of 64 records, highest first
@@ -246,10 +251,10 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
     bw.add(1, 1);                                                 // the end mark the decoder looks for
     bw.flush();
     if (bw.overflow) return 0;
-    int stream_bytes = bw.pos;
+    int stream_bytes = bw.pos - stage;
     if (bw.nbits > 0) {
         const uint64_t c = bw.cont;
-        FOR_LANES_W(l) { if (l == 0) lds[stream_bytes] = (uint8_t)c; }
+        FOR_LANES_W(l) { if (l == 0) lds[stage + stream_bytes] = (uint8_t)c; }
         stream_bytes += 1;
     }
     const int total = stream_at + stream_bytes;
@@ -282,7 +287,7 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
         }
     }
     // ---- the bit stream LDS -> frame ---------------------------------------------------------------------------------------
-    for (int c = 0; c < stream_bytes; c += 64) { FOR_LANES(l) { if (c + l < stream_bytes) out[stream_at + c + l] = lds[c + l]; } }
+    for (int c = 0; c < stream_bytes; c += 64) { FOR_LANES(l) { if (c + l < stream_bytes) out[stream_at + c + l] = lds[stage + c + l]; } }
     return total;
 }
 

@@ -898,7 +898,7 @@ def test_zstd_and_lz4hc_encoders_write_valid_chunks(eng):
                 assert rc == 0 and got == emu, (name, clevel, np.dtype(dtype).name, fam)
                 off = 0
                 for c, n in zip(got, sizes):
-                    assert 0 < len(c) <= n + 32
+                    assert 0 < len(c) <= chunk + 32                                  # (a remainder chunk of noise in a nominal buffer stays block-framed: SURVEY N7)
                     assert c[22] == codec and (c[2] >> 5) == (4 if codec == hip.ZSTD else 1) or (c[2] & 0x02)      # (memcpyed chunks keep the bits too)
                     if not (c[2] & 0x02) and it > 1:
                         assert bool(c[2] & 0x10) == (not (codec == hip.ZSTD and clevel <= 5)), (name, clevel)      # zstd splits up to level 5, lz4hc never
