@@ -180,7 +180,7 @@ def kernel_source_hash():
 
 
 def pmc_traffic(kernel, explicit=None):
-    path = explicit or os.path.join(ROOT, "profiles", "r02", "pmc_per_launch.json")
+    path = explicit or os.path.join(ROOT, "profiles", "r03", "pmc_per_launch.json")
     if not os.path.exists(path):
         return None, None
     try:
@@ -203,16 +203,16 @@ def pmc_traffic(kernel, explicit=None):
 
 def run_config5(args, rank, world, local_rank, dist, red_dev):
     """BASELINE configs[4]: 16384 x 16384 float32, 8 channels, zstd + byte shuffle over 8 GPUs -- ONE channel (1 GiB, 256 chunks
-    of 4 MiB, 32768 blocks of 32 KiB) per rank.  The chunks are what the reference writes with enums::codec::zstd at its default
-    level 9 (enums.h:18-24, blosc2/wrapper.h:74-119: c-blosc2 maps clevel 9 to ZSTD_maxCLevel(), one unsplit frame per block),
-    made OUTSIDE the timed region by the box's own libzstd through the checker's chunk layer (oracle/zstd_dl.c).  A step =
-    one batched decode of the channel (cimg_decode_zstd behind the general launch).  The compression ratio is reported
-    beside the rate (docs/concepts/compression.rst:46)."""
+    of 4 MiB, 32768 blocks of 32 KiB) per rank, with the compression ratio beside the rate (docs/concepts/compression.rst:46).
+
+    A step = compress the channel with the engine's zstd encoder (csrc/zstd_encode.h: FORMAT-VALID frames -- raw literals +
+    predefined FSE tables over the wave's LZ4 matches -- whose bytes differ from libzstd's by construction; the blosc2 level, 9 as
+    in the reference's defaults, decides only the split rule: one frame per 32 KiB block) + decompress it again (cimg_decode_zstd),
+    pixels and chunks resident in HBM.  Beside it, outside the timed region: chunks as the REFERENCE writes them (the box's libzstd
+    at clevel 9 = ZSTD_maxCLevel() under the checker's chunk layer, oracle/zstd_dl.c) decoded by the same kernel, their ratio, and
+    libzstd's own rates on the host."""
     import _oracle as O
     from cimg import hip, synth
-    if not O.zstd_available():
-        print("bench.py --config 5: no libzstd on this box to make the chunks with", file=sys.stderr)
-        sys.exit(4)
     L, _ = _oracle_batch_lib()
     W = H = 16384
     dt = np.float32
@@ -221,47 +221,36 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
     host = chan.view(np.uint8).ravel()
     N = host.size
     nchunks = N // CHUNK
-    stride = CHUNK + 64
-    comp = np.zeros(nchunks * stride, np.uint8)
-    cb = np.zeros(nchunks, np.int32)
-    p = O.cparams(4, clevel=clevel, blocksize=BLOCK, compcode=O.ZSTD)
-    cores = min(visible_cores(), 64)
-    teams = min(cores, nchunks)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    t0 = time.perf_counter()
-    piece = 32                                                          # progress every 128 MiB (clevel 9 = zstd level 22 is slow)
-    for a in range(0, nchunks, piece):
-        n = min(piece, nchunks - a)
-        r = L.orc_bench_compress(C.byref(p), vp(host[a * CHUNK:]), n, CHUNK, vp(comp[a * stride:]), stride, CHUNK + 32, vp(cb[a:]),
-                                 min(teams, n), max(1, cores // min(teams, n)))
-        assert r > 0
-        print(f"[bench --config 5] rank {rank}: libzstd clevel {clevel} made chunks {a}..{a + n - 1} of {nchunks} ({time.perf_counter() - t0:.1f} s)", file=sys.stderr, flush=True)
-    t_make = time.perf_counter() - t0
-    Cb = int(cb.sum())
-    # pack the chunks back to back (64-byte aligned), as a caller holding them would
-    offs = np.zeros(nchunks, np.int64)
-    o = 0
-    for i in range(nchunks):
-        offs[i] = o
-        o += (int(cb[i]) + 63) & ~63
-    packed = np.zeros(o + 64, np.uint8)
-    for i in range(nchunks):
-        packed[offs[i]:offs[i] + cb[i]] = comp[i * stride:i * stride + cb[i]]
-    del comp
-    d_comp = torch.from_numpy(packed).cuda()
-    d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
     raw_off = np.arange(nchunks, dtype=np.int64) * CHUNK
     nbytes = np.full(nchunks, CHUNK, np.int32)
     blocksize = np.full(nchunks, BLOCK, np.int32)
+    gstride = CHUNK + 64
+    goff = np.arange(nchunks, dtype=np.int64) * gstride
+    dest = np.full(nchunks, CHUNK + 32, np.int32)
+    d_raw = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    d_gcomp = torch.zeros(nchunks * gstride, dtype=torch.uint8, device="cuda")
     eng = hip.Engine(local_rank)
+    gp = hip.cparams(4, clevel=clevel, blocksize=BLOCK, compcode=hip.ZSTD)
 
     def step():
-        eng.decompress_device(d_comp.data_ptr(), offs, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=cb)
+        cb = eng.compress_device(gp, d_raw.data_ptr(), raw_off, nbytes, d_gcomp.data_ptr(), goff, dest)
+        eng.decompress_device(d_gcomp.data_ptr(), goff, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=cb)
+        return cb
 
-    step()
-    if not np.array_equal(d_out.cpu().numpy(), host):
+    gcb = step()
+    if not torch.equal(d_out, d_raw):
         print("bench.py --config 5: decompressed pixels differ from the input -- refusing to report a number", file=sys.stderr)
         sys.exit(3)
+    have_libzstd = O.zstd_available()
+    if have_libzstd:                                               # the real library reads the engine's chunks too (a sample)
+        sample = d_gcomp[:3 * gstride].cpu().numpy()
+        for i in range(3):
+            r, px = O.decompress(sample[i * gstride:i * gstride + int(gcb[i])])
+            if r != CHUNK or px.tobytes() != host[i * CHUNK:(i + 1) * CHUNK].tobytes():
+                print("bench.py --config 5: libzstd does not decode the GPU encoder's chunk", i, file=sys.stderr)
+                sys.exit(3)
     for _ in range(args.warmup):
         step()
     eng.enable_timing(1)
@@ -276,6 +265,7 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    Cb = int(gcb.sum())
     total_c = float(Cb)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -284,91 +274,84 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
         cs = torch.tensor([total_c], dtype=torch.float64, device=red_dev)
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         total_c = float(cs.item())
-    zms, zn = eng.kernel_time(hip.K_DECODE_ZSTD)
-    gms, gn = eng.kernel_time(hip.K_DECODE)
-    eng.enable_timing(False)
-    # ---- the compress half on the GPU: the engine's own zstd encoder (csrc/zstd_encode.h: format-valid frames, NOT libzstd's bytes;
-    # the blosc2 level only decides the split rule).  Round trip through the GPU decoder + a sample of chunks through libzstd.
-    d_raw = torch.from_numpy(host).cuda()
-    gstride = CHUNK + 64
-    d_gcomp = torch.zeros(nchunks * gstride, dtype=torch.uint8, device="cuda")
-    goff = np.arange(nchunks, dtype=np.int64) * gstride
-    gp = hip.cparams(4, clevel=clevel, blocksize=BLOCK, compcode=hip.ZSTD)
-    dest = np.full(nchunks, CHUNK + 32, np.int32)
-    gcb = eng.compress_device(gp, d_raw.data_ptr(), raw_off, nbytes, d_gcomp.data_ptr(), goff, dest)
-    d_out.zero_()
-    eng.decompress_device(d_gcomp.data_ptr(), goff, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=gcb)
-    if not np.array_equal(d_out.cpu().numpy(), host):
-        print("bench.py --config 5: the GPU zstd encoder's chunks do not decode to the input", file=sys.stderr)
-        sys.exit(3)
-    sample = d_gcomp[:3 * gstride].cpu().numpy()
-    for i in range(3):                                              # the real library reads them too
-        r, px = O.decompress(sample[i * gstride:i * gstride + int(gcb[i])])
-        if r != CHUNK or px.tobytes() != host[i * CHUNK:(i + 1) * CHUNK].tobytes():
-            print("bench.py --config 5: libzstd does not decode the GPU encoder's chunk", i, file=sys.stderr)
-            sys.exit(3)
-    eng.enable_timing(1)
-    eng.reset_timing()
-    torch.cuda.synchronize()
-    te0 = time.perf_counter()
-    enc_steps = max(2, args.steps // 2)
-    for _ in range(enc_steps):
-        eng.compress_device(gp, d_raw.data_ptr(), raw_off, nbytes, d_gcomp.data_ptr(), goff, dest)
-    torch.cuda.synchronize()
-    t_enc = (time.perf_counter() - te0) / enc_steps
     ems, en = eng.kernel_time(hip.K_ENCODE_ZSTD)
-    # ... and the decoder on the engine's own chunks (raw literals + predefined tables: the cheap corner of the format)
-    eng.reset_timing()
-    for _ in range(enc_steps):
-        eng.decompress_device(d_gcomp.data_ptr(), goff, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=gcb)
-    torch.cuda.synchronize()
-    oms, on = eng.kernel_time(hip.K_DECODE_ZSTD)
+    zms, zn = eng.kernel_time(hip.K_DECODE_ZSTD)
     eng.enable_timing(False)
-    gpu_encoder = {"what": "cimg_encode_streams_zstd (format-valid zstd frames: raw literals + predefined FSE tables over the wave's LZ4 matches; "
-                           "bytes differ from libzstd's by construction)",
-                   "compress_GBps": round(N / t_enc / 1e9, 3), "kernel_avg_us": round(ems / max(en, 1) * 1e3, 1),
-                   "compression_ratio": round(N / float(gcb.sum()), 4), "compressed_bytes": int(gcb.sum()),
-                   "decode_of_own_chunks_avg_us": round(oms / max(on, 1) * 1e3, 1),
-                   "decode_of_own_chunks_GBps": round(N / (oms / max(on, 1) * 1e-3) / 1e9, 3) if on else None,
-                   "verified": "round trip through cimg_decode_zstd on every chunk; 3 chunks through libzstd " + O.zstd_version()}
+    if not torch.equal(d_out, d_raw):
+        print("bench.py --config 5: pixels differ after the timed region", file=sys.stderr)
+        sys.exit(3)
+    e_avg_s, z_avg_s = ems / max(en, 1) * 1e-3, zms / max(zn, 1) * 1e-3
+    dom_is_enc = ems >= zms
+    out = None
     if rank == 0:
-        z_avg_s = zms / max(zn, 1) * 1e-3
         out = {
-            "metric": "decompress GB/s (uncompressed side), zstd chunks", "value": round(world * args.steps * N / elapsed / 1e9, 3), "unit": "GB/s",
+            "metric": "compress+decompress GB/s (uncompressed side), zstd", "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4] share of one rank: 1x{W}x{H} float32 per GPU, zstd clevel {clevel} (zstd level "
-                                   f"{L.orc_zstd_level_of_clevel(clevel)}, {'split planes' if clevel <= 5 else 'one frame per block'}) + byte shuffle, 32 KiB blocks, "
-                                   f"4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks), device-resident, family={args.family}; DECODE ONLY "
-                                   f"(chunks made by libzstd {O.zstd_version()} on the host, outside the timed region: {t_make:.1f} s on {cores} threads)",
+            "config": {"workload": f"BASELINE configs[4] share of one rank: 1x{W}x{H} float32 per GPU, zstd clevel {clevel} "
+                                   f"({'split planes' if clevel <= 5 else 'one frame per block'}) + byte shuffle, 32 KiB blocks, 4 MiB chunks "
+                                   f"({nchunks} chunks, {N // BLOCK} blocks), device-resident, family={args.family}; the engine's own zstd encoder "
+                                   f"(format-valid frames, NOT libzstd's bytes) and decoder",
                        "element_dtype": "float32", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": Cb,
                        "compression_ratio": round(world * N / total_c, 4),
-                       "host_libzstd_compress_GBps": round(N / t_make / 1e9, 4), "host_threads": cores,
+                       "compress_GBps": round(N / e_avg_s / 1e9, 3) if e_avg_s > 0 else None,
+                       "decompress_GBps": round(N / z_avg_s / 1e9, 3) if z_avg_s > 0 else None,
                        "parallelism": f"channels sharded by rank x{world}, no data-path collective"},
-            "roofline": {"kernel": "cimg_decode_zstd", "bound": "hbm", "achieved": round((Cb + N) / z_avg_s / 1e9, 1) if z_avg_s > 0 else None,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round((Cb + N) / z_avg_s / 1e9 / HBM_PEAK_GBPS, 5) if z_avg_s > 0 else None,
-                         "traffic": None, "algorithmic_bytes_per_launch": int(Cb + N), "avg_launch_us": round(z_avg_s * 1e6, 1)},
-            "gpu_zstd_encoder": gpu_encoder,
-            "kernels": {"cimg_decode_zstd": {"launches": zn, "avg_us": round(z_avg_s * 1e6, 1)},
-                        "cimg_decode_blocks (finds the zstd chunks)": {"launches": gn, "avg_us": round(gms / max(gn, 1) * 1e3, 1)}},
+            "roofline": {"kernel": "cimg_encode_streams_zstd" if dom_is_enc else "cimg_decode_zstd", "bound": "hbm",
+                         "achieved": round((Cb + N) / (e_avg_s if dom_is_enc else z_avg_s) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round((Cb + N) / (e_avg_s if dom_is_enc else z_avg_s) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(Cb + N), "avg_launch_us": round((e_avg_s if dom_is_enc else z_avg_s) * 1e6, 1)},
+            "kernels": {"cimg_encode_streams_zstd": {"launches": en, "avg_us": round(e_avg_s * 1e6, 1)},
+                        "cimg_decode_zstd": {"launches": zn, "avg_us": round(z_avg_s * 1e6, 1)}},
         }
-        if not args.no_cpu_baseline and world == 1:
-            # the checker's chunk layer + the box's libzstd decoding the same chunks on this GPU's share of the host (16 threads)
-            outb = np.zeros(N, np.uint8)
-            thr = min(visible_cores(), 16)
-            comp2 = np.zeros(nchunks * stride, np.uint8)
-            for i in range(nchunks):
-                comp2[i * stride:i * stride + cb[i]] = packed[offs[i]:offs[i] + cb[i]]
-            t0 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t0 < 8.0:
-                d = L.orc_bench_decompress(vp(comp2), nchunks, stride, vp(cb), vp(outb), CHUNK, min(thr, nchunks), 1)
-                assert d == N
-                reps += 1
-            td = time.perf_counter() - t0
-            assert outb.tobytes() == host.tobytes()
-            out["cpu_baseline"] = {"value": round(reps * N / td / 1e9, 3), "unit": "GB/s", "cores": thr, "kind": "port",
-                                   "sample": f"libzstd {O.zstd_version()} ZSTD_decompress under the oracle's chunk layer, the same {nchunks} chunks, {reps} passes in {td:.1f} s"}
+    # ---- chunks as the reference writes them: libzstd on the host (outside the timed region), decoded by the same kernel -----------
+    if rank == 0 and world == 1 and have_libzstd and not args.no_cpu_baseline:
+        stride = CHUNK + 64
+        comp = np.zeros(nchunks * stride, np.uint8)
+        cb = np.zeros(nchunks, np.int32)
+        p = O.cparams(4, clevel=clevel, blocksize=BLOCK, compcode=O.ZSTD)
+        cores = min(visible_cores(), 64)
+        teams = min(cores, nchunks)
+        t0 = time.perf_counter()
+        piece = 32                                                      # progress every 128 MiB (clevel 9 = zstd level 22 is slow)
+        for a in range(0, nchunks, piece):
+            n = min(piece, nchunks - a)
+            r = L.orc_bench_compress(C.byref(p), vp(host[a * CHUNK:]), n, CHUNK, vp(comp[a * stride:]), stride, CHUNK + 32, vp(cb[a:]),
+                                     min(teams, n), max(1, cores // min(teams, n)))
+            assert r > 0
+            print(f"[bench --config 5] libzstd clevel {clevel} made chunks {a}..{a + n - 1} of {nchunks} ({time.perf_counter() - t0:.1f} s)", file=sys.stderr, flush=True)
+        t_make = time.perf_counter() - t0
+        d_ref = torch.from_numpy(comp).cuda()
+        roff = np.arange(nchunks, dtype=np.int64) * stride
+        d_out.zero_()
+        eng.decompress_device(d_ref.data_ptr(), roff, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=cb)
+        ok = torch.equal(d_out, d_raw)
+        eng.enable_timing(1)
+        eng.reset_timing()
+        for _ in range(3):
+            eng.decompress_device(d_ref.data_ptr(), roff, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=cb)
+        rms, rn = eng.kernel_time(hip.K_DECODE_ZSTD)
+        eng.enable_timing(False)
+        thr = min(visible_cores(), 16)
+        outb = np.zeros(N, np.uint8)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 6.0:
+            d = L.orc_bench_decompress(vp(comp), nchunks, stride, vp(cb), vp(outb), CHUNK, min(thr, nchunks), 1)
+            assert d == N
+            reps += 1
+        td = time.perf_counter() - t0
+        out["reference_chunks"] = {
+            "what": f"chunks as c-blosc2 would write them: libzstd {O.zstd_version()} at clevel {clevel} (zstd level {L.orc_zstd_level_of_clevel(clevel)}) under the checker's chunk layer",
+            "compression_ratio": round(N / float(cb.sum()), 4), "decoded_bit_exact_by_cimg_decode_zstd": bool(ok),
+            "gpu_decode_avg_us": round(rms / max(rn, 1) * 1e3, 1), "gpu_decode_GBps": round(N / (rms / max(rn, 1) * 1e-3) / 1e9, 3) if rn else None,
+            "host_libzstd_compress_GBps": round(N / t_make / 1e9, 4), "host_compress_threads": cores,
+            "host_libzstd_decompress_GBps": round(reps * N / td / 1e9, 3), "host_decompress_threads": thr}
+        out["cpu_baseline"] = {"value": round(2 * N / (t_make + td / reps) / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+                               "compress_GBps": round(N / t_make / 1e9, 4), "decompress_GBps": round(reps * N / td / 1e9, 3),
+                               "sample": f"libzstd {O.zstd_version()} under the oracle's chunk layer on the same channel: one compress pass at clevel {clevel} on {cores} threads "
+                                         f"({t_make:.1f} s), {reps} decompress passes on {thr} threads ({td:.1f} s)"}
+    if rank == 0:
         print(json.dumps(out))
     eng.close()
     if dist is not None:
