@@ -61,7 +61,8 @@ struct EncodeArgs {
     uint32_t* zstd_seq;       // wave w owns zstd_seq + w * zstd_seq_stride (dwords)
     int32_t zstd_seq_stride;
     const ZstdEncTables* zstd_tables;
-    uint32_t queue_base;      // the queue head counts on from batch to batch: item = pop - queue_base (nothing resets it in between)
+    uint32_t queue_base;      // the queue head counts on from batch to batch: item = pop - queue_base + nwaves (nothing resets it in between)
+    int32_t nwaves;           // waves of the launch: wave w takes item w first, the queue deals out the items behind those
     // ---- chunks assembled INSIDE the launch (assemble != 0; round 3) ---------------------------------------------------------
     // A wave remembers the items it encoded (a linked list through next_item[]); the wave that finishes the last stream of a
     // chunk lays the chunk out (LayoutChunk: bstarts, header, the running-destsize rule) and raises ready[chunk]; when the work
@@ -1243,7 +1244,7 @@ struct EncodeStream {
     // that when it moves queue_base on), then -- when the batch is assembled in place -- copy blocks of finished chunks
     CIMG_DEV void run()
     {
-        int items, assemble;
+        int items, assemble, nwaves;
         uint32_t* queue;
         uint32_t qbase;
         {
@@ -1252,15 +1253,24 @@ struct EncodeStream {
             queue = a->queue;
             qbase = a->queue_base;
             assemble = a->assemble;
+            nwaves = a->nwaves;
         }
+        // The FIRST item of wave w is item w, without asking: device-scope atomics on one address are served one after the other
+        // (about 10 ns each, measured on the decode side), so a launch whose 1280 waves all pop at once starts its last chain
+        // 13 us late.  The queue hands out the items from nwaves on.
         // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
         int last = -1;                                           // the items this wave encoded, newest first (next_item[])
-        for (int pops = 0; pops <= items; ++pops) {
-            LV<uint32_t> got;
-            FOR_LANES(l) { got[l] = 0; }
-            FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(queue); }
-            const int item = uni((int)(readlane(got, 0) - qbase));
-            if (item >= items || item < 0) break;
+        for (int pops = 0; pops <= items + 1; ++pops) {
+            int item;
+            if (pops == 0 && w < items) {
+                item = w;
+            } else {
+                LV<uint32_t> got;
+                FOR_LANES(l) { got[l] = 0; }
+                FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(queue); }
+                item = uni((int)(readlane(got, 0) - qbase)) + nwaves;
+                if (item >= items || item < nwaves) break;
+            }
             int chunk = 0;
             const int finished = run_item(item, chunk);
             if (assemble && finished > 0) last = encode_account(ap, item, last, chunk, finished);

@@ -591,7 +591,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks,
                       nullptr, 0, nullptr,
-                      e->qbase[split], fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
+                      e->qbase[split], 0, fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
                       sync + 16, sync + 16 + nslots, (int32_t*)e->next_item.p, e->fold_gen};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ, zst = plan.cp.compcode == CODEC_ZSTD;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : zst ? cimg_encode_streams_zstd : cimg_encode_streams;
@@ -641,9 +641,10 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             }
             ea.zstd_seq = (uint32_t*)e->zstd_seq.p; ea.zstd_seq_stride = stride; ea.zstd_tables = (const ZstdEncTables*)e->zstd_tables.p;
         }
+        ea.nwaves = grid * gang;
         if ((rc = e->launch(zst ? CIMG_K_ENCODE_ZSTD : CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes))) return rc;
-        // every wave of the launch pops exactly one item past the end
-        e->qbase[split] += (uint32_t)items + (uint32_t)grid * (uint32_t)gang;
+        // the queue deals out the items behind the first nwaves, and every wave pops exactly one past the end
+        e->qbase[split] += (uint32_t)(items - std::min(items, ea.nwaves)) + (uint32_t)ea.nwaves;
     }
     if (leftovers) {
         AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,

@@ -79,14 +79,18 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         // 1: every block whole; 2: the first half whole, the rest plane by plane (the mixed queue of a small batch)
         const int whole_blocks = !block_items ? 0 : (g_emu_block_items == 2 ? plan.total_blocks / 2 : plan.total_blocks);
         const int zstride = 2 * (plan.cp.max_blocksize / 4 + 64);
-        std::vector<uint32_t> zseq((size_t)zstride * 3, 0xA5A5A5A5u);
+        std::vector<uint32_t> zseq((size_t)zstride * 4, 0xA5A5A5A5u);
         static ZstdEncTables ztabs;
         zstd_build_enc_tables(&ztabs);
+        // (the waves run one after the other here, so a wave that waits for a chunk another wave still has to finish would wait for
+        // ever: with in-launch assembly ONE wave does everything; three waves -- the static first items of waves 1 and 2 -- where the
+        // two assembly kernels run behind the launch)
+        const int emu_waves = folded ? 1 : 3;
         std::vector<int32_t> next_item((size_t)encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks) + 1, -7);
         EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, whole_blocks,
                       zseq.data(), zstride, &ztabs,
-                      qbase, fold ? 1 : 0, comp, layout.data(), layout_host.data(), chunk_count.data(), ready.data(), next_item.data(), gen};
-        for (int w = 0; w < 3; w++) {          // persistent workgroups; the first one drains the queue
+                      qbase, emu_waves, fold ? 1 : 0, comp, layout.data(), layout_host.data(), chunk_count.data(), ready.data(), next_item.data(), gen};
+        for (int w = 0; w < emu_waves; w++) {  // persistent waves: each takes item w first, the first one then drains the queue
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
             else if (plan.cp.compcode == CODEC_ZSTD) { EncodeStream<CODEC_ZSTD> es(&ea, lds.data(), w); es.run(); }
