@@ -181,7 +181,9 @@ struct DecodeLeanWave {
         // would push the whole object, pre[] included, to scratch)
         const bool raw0 = kind[0] == 1, raw1 = kind[1] == 1;
         const int raw_at = raw0 ? at[0] : at[1];
-        const bool want_pre = ts == 2 && neblock == 16384 && (raw0 != raw1);
+        // (only next to a CODED plane: the un-shuffle of the register form takes the other plane from LDS.  A block whose other
+        // plane is a run token -- 16-bit pixels below 256 with a noisy low byte -- goes the plane_word way.)
+        const bool want_pre = coded == 1 && ts == 2 && neblock == 16384 && (raw0 != raw1);
         if (coded == 1) {
             const int park = rs - round16(lz_cs);
             LEAN_STAMP(a.dbg, h.b, 1);                                            // header walk done

@@ -183,6 +183,13 @@ def test_lean_decode_kernel_takes_the_single_coded_plane_blocks():
     zero[::7, ::5] = 3                                                # low plane codes, high plane is a run token
     _check_batch(np.uint16, zero, 65536)
     assert E.lean_blocks() > 0
+    # 16-bit pixels below 256 with a noisy low byte: low plane stored raw, high plane a zero run, NO coded plane (a round-3 build
+    # requested the stored plane into registers here and un-shuffled it against whatever the last block left in LDS)
+    rng = np.random.default_rng(11)
+    quiet = ((np.arange(300 * 200).reshape(200, 300) // 37 % 251) + rng.integers(0, 3, (200, 300))).astype(np.uint16)
+    _check_batch(np.uint16, quiet, 120000)
+    _check_batch(np.uint16, rng.integers(0, 256, (64, 1024)).astype(np.uint16), 65536)
+    assert E.lean_blocks() > 0
     _check_batch(np.uint8, synth.natural_channel(np.uint8, 512, 64), 16384)      # typesize 1: never lean
     assert E.lean_blocks() == 0
     _check_batch(np.uint16, synth.natural_channel(np.uint16, 1024, 64), 40000)   # ragged: leftover blocks stay general

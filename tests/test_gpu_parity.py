@@ -490,6 +490,20 @@ def test_lean_and_general_decode_agree_on_mixed_batches(eng):
     assert list(status[:3]) == [0, 0, 0]
     assert outs[0].tobytes() == t.tobytes() and outs[1].tobytes() == nat.tobytes() and outs[2].tobytes() == u8.tobytes()
     assert status[3] < 0 or outs[3].tobytes() != t.tobytes()
+    # lean blocks WITHOUT a coded plane: 16-bit pixels below 256 with a noisy low byte (low plane stored raw, high plane a zero run),
+    # decoded right behind blocks that do have one -- so that whatever those left in LDS would show (a round-3 build un-shuffled the
+    # stored plane against it); lz4 and blosclz, which store different blocks raw
+    rng = np.random.default_rng(11)
+    quiet = ((np.arange(300 * 200).reshape(200, 300) // 37 % 251) + rng.integers(0, 3, (200, 300))).astype(np.uint16).view(np.uint8).ravel()
+    noisy = rng.integers(0, 256, (512, 1024)).astype(np.uint16).view(np.uint8).ravel()
+    for codec in (hip.LZ4, hip.BLOSCLZ):
+        cs = []
+        for raw in (t, quiet, noisy, t, quiet):
+            cs += eng.compress_host(hip.cparams(2, compcode=codec), raw, [raw.size], [raw.size + 32])
+        outs, status = eng.decompress_host(cs)
+        assert not status.any()
+        for o, raw in zip(outs, (t, quiet, noisy, t, quiet)):
+            assert o.tobytes() == raw.tobytes(), codec
 
 
 def test_unusual_typesizes(eng):
