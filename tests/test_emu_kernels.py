@@ -346,3 +346,48 @@ def test_chunks_assembled_inside_the_encode_launch_equal_the_two_kernel_path():
             r, want = O.compress(O.cparams(2), src[off:off + s], destsize=dest)
             assert c == want
             off += s
+
+
+def plane_kind_blocks(ts, rng):
+    """One 32 KiB block per combination of plane kinds -- coded (compressible), stored (noise), run (one value) -- for every byte
+    plane of a `ts`-byte type: 9 blocks for 2-byte, 81 for 4-byte elements.  Returns the pixels as bytes (blocks back to back)."""
+    import itertools
+    ne = 32768 // ts
+    blocks = []
+    for kinds in itertools.product("crk", repeat=ts):
+        planes = []
+        for k in kinds:
+            if k == "c":
+                p = (np.arange(ne) // int(rng.integers(3, 70)) % 200).astype(np.uint8)
+                p[rng.integers(0, ne, 40)] ^= 0x55
+            elif k == "r":
+                p = rng.integers(0, 256, ne, dtype=np.uint8)
+            else:
+                p = np.full(ne, int(rng.integers(0, 256)), np.uint8)
+            planes.append(p)
+        blocks.append(np.stack(planes, axis=1).ravel())          # element i = (plane 0 byte, plane 1 byte, ...)
+    return np.concatenate(blocks)
+
+
+@pytest.mark.parametrize("compcode", [1, 0])
+def test_every_combination_of_plane_kinds_decodes(compcode):
+    """The lean decode kernel takes blocks by the KINDS of their planes (at most one coded, the others stored or run tokens) and
+    has a register path for the commonest shape; this walks all 9 / 81 combinations for 2- and 4-byte elements, in an order that
+    puts every shape behind every other kind of LDS content, for LZ4 and BloscLZ.  Bytes against the oracle, pixels back."""
+    rng = np.random.default_rng(77 + compcode)
+    for ts in (2, 4):
+        raw = plane_kind_blocks(ts, rng)
+        sizes = [raw.size]
+        rc, cb, chunks = E.compress_batch(E.cparams(ts, compcode=compcode), raw, sizes, [raw.size + 32])
+        assert rc == 0
+        r, want = O.compress(O.cparams(ts, compcode=compcode), raw, destsize=raw.size + 32)
+        assert chunks[0] == want
+        for shape in (1, 2, 5):
+            E.lib().emu_set_lean_shape(shape)
+            try:
+                rc, st, outs = E.decompress_batch(chunks, sizes, [32768])
+            finally:
+                E.lib().emu_set_lean_shape(-1)
+            assert rc == 0 and not any(st)
+            bad = np.nonzero(outs[0] != raw)[0]
+            assert bad.size == 0, (ts, compcode, shape, "first wrong byte %d = block %d" % (bad[0], bad[0] // 32768))

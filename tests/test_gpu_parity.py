@@ -927,3 +927,23 @@ def test_zstd_and_lz4hc_encoders_write_valid_chunks(eng):
                 outs, status = eng.decompress_host(got)
                 assert not status.any() and b"".join(o.tobytes() for o in outs) == raw.tobytes(), (name, clevel, fam)
                 print(f"{name} clevel {clevel} {np.dtype(dtype).name} {fam}: ratio {raw.size / sum(map(len, got)):.3f}")
+
+
+@pytest.mark.parametrize("compcode", [hip.LZ4, hip.BLOSCLZ])
+def test_every_combination_of_plane_kinds_decodes_on_the_gpu(eng, compcode):
+    """All 9 / 81 combinations of plane kinds (coded / stored / run) of a 32 KiB block of 2- / 4-byte elements, back to back in
+    one chunk and again with the blocks in reverse order (tests/test_emu_kernels.py: plane_kind_blocks): the lean kernel's shapes,
+    each behind every other kind of LDS content.  Bytes against the oracle, pixels back."""
+    from test_emu_kernels import plane_kind_blocks
+    rng = np.random.default_rng(77 + compcode)
+    for ts in (2, 4):
+        fwd = plane_kind_blocks(ts, rng)
+        rev = np.ascontiguousarray(fwd.reshape(-1, 32768)[::-1]).ravel()
+        for raw in (fwd, rev):
+            (c,) = eng.compress_host(hip.cparams(ts, compcode=compcode), raw, [raw.size], [raw.size + 32])
+            assert c == O.compress(O.cparams(ts, compcode=compcode), raw, destsize=raw.size + 32)[1]
+            outs, status = eng.decompress_host([c, c, c])                  # three copies: blocks also meet across chunk boundaries
+            assert not status.any()
+            for o in outs:
+                bad = np.nonzero(o != raw)[0]
+                assert bad.size == 0, (ts, compcode, "first wrong byte %d = block %d" % (bad[0], bad[0] // 32768))
