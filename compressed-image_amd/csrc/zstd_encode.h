@@ -10,7 +10,7 @@
 // Shape of a frame: magic, frame header (single segment, content size), ONE compressed block:
 //     literals section   Raw_Literals_Block: the literal runs of all sequences back to back, then the bytes behind the last match
 //     sequences section  the (literal length, offset, match length) triples, FSE-coded with the three PREDEFINED distributions
-//                        (no table description in the stream), offsets always as real offsets (offset + 3: never a repeat code)
+//                        (no table description in the stream); an offset equal to the previous sequence's is the first repeat offset
 // The triples come from the wave's LZ4 match finder (encode_kernel.h: lz4_encode_body<true>, windows of 64 probes, table in LDS)
 // at acceleration 1 -- the blosc2 level only decides, as in c-blosc2, whether a block is split into byte planes (clevel <= 5).
 // A frame that does not come out smaller than its input is not written: the stream is then stored raw, as c-blosc2 does when
@@ -215,16 +215,23 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
     // ---- FSE: the last sequence first ---------------------------------------------------------------------------------------
     uint32_t st_ll = 0, st_of = 0, st_ml = 0;
     for (int base = ((nseq - 1) >> 6) << 6; base >= 0; base -= 64) {          // batches of 64 records, highest first
-        LV<uint32_t> r0, r1;
+        // (rp: the record BEFORE each one -- a sequence whose offset repeats the previous sequence's, and that has literals, is
+        // coded as the first repeat offset, Offset_Value 1: no extra bits.  The decoder's first repeat offset always IS the previous
+        // sequence's offset here -- a real offset becomes it, a repeat leaves it -- and starts at 1 for the first sequence; the
+        // second and third repeat offsets are never used, so their bookkeeping cannot matter.  A sequence WITHOUT literals reads
+        // Offset_Value 1 as the second repeat offset: it keeps its real offset.)
+        LV<uint32_t> r0, r1, rp;
         FOR_LANES(l) {
             const int i = imin(base + l, nseq - 1);
             r0[l] = sink.seq[2 * (size_t)i];
             r1[l] = sink.seq[2 * (size_t)i + 1];
+            rp[l] = i > 0 ? (sink.seq[2 * (size_t)i - 1] & 0xFFFFu) : 1u;
         }
         const int top = imin(63, nseq - 1 - base);
         for (int k = top; k >= 0; --k) {
             const uint32_t w0 = readlane(r0, k), w1 = readlane(r1, k);
-            const int ll = (int)w0, ml = (int)(w1 >> 16), off_base = (int)(w1 & 0xFFFF) + 3;
+            const int ll = (int)w0, ml = (int)(w1 >> 16);
+            const int off_base = ((w1 & 0xFFFF) == readlane(rp, k) && ll > 0) ? 1 : (int)(w1 & 0xFFFF) + 3;
             const int llc = zstd_ll_code(ll), mlc = zstd_ml_code(ml), ofc = zstd_highbit((uint32_t)off_base);
             const int llb = zstd_ll_bits(llc), mlb = zstd_ml_bits(mlc);
             if (base + k == nseq - 1) {
