@@ -36,7 +36,8 @@ typedef struct cimg_cparams {
     int32_t typesize;        /* sizeof(T) */
     int32_t clevel;          /* 0..9 */
     int32_t blocksize;       /* bytes; constants.h:11 default 32768 */
-    int32_t compcode;        /* BLOSC_LZ4 = 1 (BLOSC_BLOSCLZ = 0, BLOSC_LZ4HC = 2, BLOSC_ZSTD = 5) */
+    int32_t compcode;        /* BLOSC_LZ4 = 1, BLOSC_BLOSCLZ = 0: the CPU codec's bytes; BLOSC_LZ4HC = 2, BLOSC_ZSTD = 5: format-valid
+                              * streams (any LZ4 / zstd decoder reads them), NOT liblz4-HC's / libzstd's bytes.  BLOSC_ZLIB: refused. */
     int32_t splitmode;       /* BLOSC_AUTO_SPLIT = 3 */
     uint8_t filters[6];      /* default {0,0,0,0,0,BLOSC_SHUFFLE} */
     uint8_t filters_meta[6];
@@ -60,6 +61,8 @@ void* cimg_engine_stream(cimg_engine* e);                     /* the hipStream_t
  * d_comp + comp_off[i] with capacity destsize[i] (what the reference passes as the dest span:
  * nominal chunk size + BLOSC2_MAX_OVERHEAD, schunk.h:73).  Offset / size arrays are HOST arrays.
  * cbytes[i] receives what blosc2_compress_ctx would return for that chunk (0 = does not fit).
+ * One encode launch per kind of block (split into byte planes / unsplit) does everything: the waves that encoded a chunk also
+ * lay it out and copy it into place.
  * The call returns after the results are on the host (one stream sync). */
 int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
                                const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
