@@ -65,6 +65,7 @@ inline int plan_chunk(const HostCParams& p, int32_t nbytes, int32_t destsize, Ch
     } else {
         if (p.blocksize <= 0) return ERR_INVALID_PARAM;     // automatic block size is not on the path
         bs = p.blocksize;
+        if (bs < MIN_BUFFERSIZE) bs = MIN_BUFFERSIZE;       // a forced block size below 32 bytes is raised to 32 (upstream compute_blocksize, recalled)
         if (bs > nbytes) bs = nbytes;
         if (bs > ts) bs = bs / ts * ts;
     }

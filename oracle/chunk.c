@@ -89,6 +89,8 @@ int orc_chunk_geometry(const orc_cparams* p, int32_t nbytes, orc_geometry* g)
     } else {
         if (p->blocksize <= 0) return ORC_ERR_INVALID_PARAM;   /* automatic block size: not on the path */
         bs = p->blocksize;
+        if (bs < MIN_BUFFERSIZE) bs = MIN_BUFFERSIZE;   /* SURVEY N2 [UPSTREAM-RECALL]: compute_blocksize raises a forced block size below
+                                                        * BLOSC_MIN_BUFFERSIZE to it, then clips to nbytes, then rounds down to the typesize */
         if (bs > nbytes) bs = nbytes;
         if (bs > ts) bs = bs / ts * ts;
     }
