@@ -270,6 +270,32 @@ class Engine:
             self._check(rc)
         return status
 
+    def roundtrip_calls(self, p, d_raw, raw_off, nbytes, d_comp, comp_off, destsize, blocksize, d_out):
+        """The four calls of a device-resident round trip (compress _begin, decompress _begin, both _fetch) with their arguments
+        marshalled ONCE: returns step() -> cbytes.  For callers that repeat the same batch geometry (bench.py): the per-call numpy
+        -> ctypes conversions of the methods above cost the host more than the C calls themselves."""
+        L = load()
+        raw_off, comp_off, nbytes, destsize, blocksize = _i64(raw_off), _i64(comp_off), _i32(nbytes), _i32(destsize), _i32(blocksize)
+        n = int(nbytes.size)
+        cbytes = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int32)
+        keep = (raw_off, comp_off, nbytes, destsize, blocksize, cbytes, status, p)          # the pointers below point into these
+        h, pp = self.handle, C.byref(p)
+        a_raw, a_comp, a_nb, a_ds, a_bs = _ptr(raw_off), _ptr(comp_off), _ptr(nbytes), _ptr(destsize), _ptr(blocksize)
+        a_cb, a_st = _ptr(cbytes), _ptr(status)
+        vr, vc, vo = C.c_void_p(d_raw), C.c_void_p(d_comp), C.c_void_p(d_out)
+        cb_begin, db_begin, cb_fetch, db_fetch = (L.cimg_compress_batch_device_begin, L.cimg_decompress_batch_device_begin,
+                                                  L.cimg_compress_batch_device_fetch, L.cimg_decompress_batch_device_fetch)
+        check = self._check
+
+        def step(_keep=keep):
+            check(cb_begin(h, pp, n, vr, a_raw, a_nb, vc, a_comp, a_ds))
+            check(db_begin(h, n, vc, a_comp, a_nb, a_bs, vo, a_raw))
+            check(cb_fetch(h, n, a_cb))
+            check(db_fetch(h, a_st))
+            return cbytes
+        return step
+
     # ---- host-resident batches ----
     def compress_host(self, p, raw, nbytes, destsize):
         """raw: numpy array holding the chunks back to back.  Returns list of chunk bytes (b'' = does not fit)."""
