@@ -30,6 +30,7 @@ for name, sl in (("first half of the queue (high-byte planes)", slice(0, half)),
     d = dur[sl]
     print("  %-44s duration us: mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f;  starts %.1f..%.1f  ends ..%.1f" % (name, d.mean(), *np.percentile(d, [10, 50, 90]), d.max(), start[sl].min(), start[sl].max(), end[sl].max()))
 # per workgroup: items taken, busy time, last end
+wg = np.unique(wg, return_inverse=True)[1]
 last = np.zeros(wg.max() + 1); busy = np.zeros(wg.max() + 1); cnt = np.zeros(wg.max() + 1, dtype=int); hi = np.zeros(wg.max() + 1, dtype=int)
 np.maximum.at(last, wg, end); np.add.at(busy, wg, dur); np.add.at(cnt, wg, 1); np.add.at(hi, wg[:half], 1)
 print("  per workgroup: items mean %.2f; high-byte planes taken histogram %s" % (cnt.mean(), np.bincount(hi).tolist()))
