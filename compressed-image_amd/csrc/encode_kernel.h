@@ -86,7 +86,7 @@ enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
 // LDS of one stream workgroup: the plane (padded to 16), then the hash table
 inline int encode_lds_bytes(int stream_bytes, int compcode = CODEC_LZ4)
 {
-    return compcode == CODEC_BLOSCLZ ? blz_encode_lds_bytes(stream_bytes) : round16(stream_bytes) + LZ4_HASH_BYTES;
+    return compcode == CODEC_BLOSCLZ ? blz_encode_lds_bytes(stream_bytes) : round16(stream_bytes) + (compcode == CODEC_ZSTD ? (2 << ZSTD_ENC_HASH_BITS) : LZ4_HASH_BYTES);
 }
 // Work items of a launch.  Streams differ in cost by an order of magnitude and the hardware places
 // workgroups on CUs round-robin, not first-free, so the launch is a set of persistent workgroups that
@@ -114,7 +114,8 @@ extern long g_emu_windows, g_emu_matches, g_emu_collisions;   // test-side stati
 #define CIMG_STAT(x) ((void)0)
 #endif
 
-CIMG_DEV uint32_t lz4_hash(uint32_t v) { return (v * 2654435761u) >> 19; }
+template <int HB = 13>
+CIMG_DEV uint32_t lz4_hash(uint32_t v) { return (v * 2654435761u) >> (32 - HB); }
 // sum_{x=0}^{n-1} (x >> 6)
 CIMG_DEV int skip_prefix(int n) { const int q = n >> 6, r = n & 63; return q * (32 * (q - 1) + r); }
 
@@ -261,6 +262,7 @@ CIMG_DEV bool emit_pending(const uint8_t* in, cimg_global_u8p out, int cap, int&
 // one owns the slot and has the earlier one as its candidate); three or more, or any candidate that compares equal, end
 // the walk with "maybe": the caller clears the table again and runs the full encoder, which costs a compressible plane one
 // wasted window.  Returns true when the search reached the end of the plane without a match: the block is its literals.
+template <int HB = 13>
 CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n, int s64, int f64, int mflimit_p1)
 {
     bool verdict = false;                                               // one way out of the loop (see lz4_encode_body)
@@ -282,7 +284,7 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
             }
             if (!~ballot(in2)) {
                 LV<uint32_t> v1, v2, h1, h2, o1, o2, r1, r2, c1, c2;
-                FOR_LANES(l) { v1[l] = lds_ld32u(in, p1[l]); v2[l] = lds_ld32u(in, p2[l]); h1[l] = lz4_hash(v1[l]); h2[l] = lz4_hash(v2[l]); }
+                FOR_LANES(l) { v1[l] = lds_ld32u(in, p1[l]); v2[l] = lds_ld32u(in, p2[l]); h1[l] = lz4_hash<HB>(v1[l]); h2[l] = lz4_hash<HB>(v2[l]); }
                 FOR_LANES(l) { o1[l] = tab16[h1[l]]; }
                 FOR_LANES_W(l) { tab16[h1[l]] = (uint16_t)p1[l]; }
                 FOR_LANES(l) { r1[l] = tab16[h1[l]]; }
@@ -311,7 +313,7 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
         if (!in_mask) { verdict = true; break; }
         LV<uint32_t> v, h, old, rb, cv;
         LV<bool> lost, equal;
-        FOR_LANES(l) { v[l] = lds_ld32u(in, inside[l] ? pos[l] : 0); h[l] = lz4_hash(v[l]); }
+        FOR_LANES(l) { v[l] = lds_ld32u(in, inside[l] ? pos[l] : 0); h[l] = lz4_hash<HB>(v[l]); }
         FOR_LANES(l) { old[l] = tab16[h[l]]; }
         FOR_LANES_W(l) { if (inside[l]) tab16[h[l]] = (uint16_t)pos[l]; }
         FOR_LANES(l) { rb[l] = tab16[h[l]]; cv[l] = lds_ld32u(in, (int)old[l]); }
@@ -349,6 +351,9 @@ CIMG_DEV bool lz4_no_match_at_all(const uint8_t* in, cimg_lds_vu16p tab16, int n
 template <bool SEQ = false>
 CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* out_generic, int cap, int accel, int& need_out, uint64_t* dbg = nullptr, int item = 0, SeqSink* sink = nullptr)
 {
+    // 13 bits = LZ4's byU16 table, which the byte-pinned LZ4 stream needs; the zstd frames around the same match finder are pinned
+    // to nothing, and a 4096-slot table lets a fourth chain of 32 KiB streams live on a CU (zstd_encode.h)
+    constexpr int HB = SEQ ? ZSTD_ENC_HASH_BITS : 13;
     cimg_global_u8p out = CIMG_AS_GLOBAL(out_generic);
     CIMG_PROF_DECL;
     (void)dbg; (void)item;
@@ -358,7 +363,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
     cimg_lds_vu16p tab16 = CIMG_AS_LDS_VU16(tab);
     {
         const u128 z = {0, 0, 0, 0};
-        for (int u0 = 0; u0 < LZ4_HASH_BYTES / 16; u0 += 64) {
+        for (int u0 = 0; u0 < (2 << HB) / 16; u0 += 64) {
             FOR_LANES(l) { st128a(tab + 16 * (u0 + l), z); }
         }
     }
@@ -373,11 +378,11 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
 
     bool hopeless = false;
     if (n >= 13 + 64) {
-        hopeless = lz4_no_match_at_all(in, tab16, n, s64, f64, mflimit_p1);
+        hopeless = lz4_no_match_at_all<HB>(in, tab16, n, s64, f64, mflimit_p1);
         if (hopeless) anchor = 0;
         else {
             const u128 z = {0, 0, 0, 0};
-            for (int u0 = 0; u0 < LZ4_HASH_BYTES / 16; u0 += 64) {
+            for (int u0 = 0; u0 < (2 << HB) / 16; u0 += 64) {
                 FOR_LANES(l) { st128a(tab + 16 * (u0 + l), z); }
             }
         }
@@ -386,7 +391,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
         {   // first byte
             LV<uint32_t> v0;
             FOR_LANES(l) { v0[l] = lds_ld32u(in, 0); }
-            FOR_LANES_W(l) { tab16[lz4_hash(v0[l])] = 0; }              // every lane: same slot, same value
+            FOR_LANES_W(l) { tab16[lz4_hash<HB>(v0[l])] = 0; }              // every lane: same slot, same value
         }
         CIMG_PROF_LAP(0);                                  // table clear + first byte
         int sstart = 1;     // search start position
@@ -416,9 +421,9 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             // skipped: slot read + run-length scan in one LDS round trip, candidate check in a second.
             auto run_path = [&](const uint32_t v0, const uint32_t backv) {
                 const int ip0 = sstart - 1;
-                const uint32_t h0 = lz4_hash(v0);
+                const uint32_t h0 = lz4_hash<HB>(v0);
                 const uint32_t bbbb = (v0 & 0xFF) * 0x01010101u;            // v0 == v1 means v0 is four equal bytes
-                FOR_LANES_W(l) { tab16[lz4_hash(backv)] = (uint16_t)(sstart - 3); }   // the "put(ip - 2)" refill (pre == 1 on every call)
+                FOR_LANES_W(l) { tab16[lz4_hash<HB>(backv)] = (uint16_t)(sstart - 3); }   // the "put(ip - 2)" refill (pre == 1 on every call)
                 LV<uint32_t> slot, scan;
                 LV<uint32_t> before;
                 FOR_LANES(l) {
@@ -577,11 +582,11 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     CIMG_PROF_LAP(2); CIMG_PROF_COUNT(0);
                     CIMG_SEQUENCE_IN_HEAD(true)
                 } else {
-                    const uint32_t h0 = lz4_hash(v0), h1 = lz4_hash(v1), h2 = lz4_hash(v2);
+                    const uint32_t h0 = lz4_hash<HB>(v0), h1 = lz4_hash<HB>(v1), h2 = lz4_hash<HB>(v2);
                     // a probe whose hash equals an EARLIER probe's would have to see that probe's write: only hits before
                     // the first such probe are taken ("read all slots, then write" equals sequential LZ4 up to there)
                     const int clean = h1 == h0 ? 1 : ((h2 == h0 || h2 == h1) ? 2 : 3);    // probes 0 .. clean - 1 have pairwise different hashes
-                    FOR_LANES_W(l) { tab16[lz4_hash(w0)] = (uint16_t)(sstart - 3); }
+                    FOR_LANES_W(l) { tab16[lz4_hash<HB>(w0)] = (uint16_t)(sstart - 3); }
                     LV<uint32_t> hl, vl, old3;
                     LV<bool> hit3;
                     FOR_LANES(l) {
@@ -620,7 +625,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             if (headed) {
                 const uint32_t w0 = readlane(Wn, 0), w1 = readlane(Wn, 1);
                 const uint32_t v0 = (w0 >> 16) | (w1 << 16), v1 = (w0 >> 24) | (w1 << 8), v2 = w1;
-                const uint32_t h0 = lz4_hash(v0), h1 = lz4_hash(v1), h2 = lz4_hash(v2);
+                const uint32_t h0 = lz4_hash<HB>(v0), h1 = lz4_hash<HB>(v1), h2 = lz4_hash<HB>(v2);
                 const bool e21 = h2 == h1;
                 if ((e21 && v2 == v1) || (!e21 && h2 == h0 && v2 == v0)) {
                     // the three probes in order (the refill of ip - 2 was written by the head); of two sharing a slot the
@@ -648,7 +653,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     pos[l] = first + l;
                     valid[l] = l < nv;
                     v[l] = lds_ld32u(in, l < nv ? first + l : 0);
-                    h[l] = lz4_hash(v[l]);
+                    h[l] = lz4_hash<HB>(v[l]);
                     back[l] = lds_ld32u(in, backpos);
                 }
             } else {
@@ -660,7 +665,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     pos[l] = p;
                     valid[l] = t < 0 || p + gap <= mflimit_p1;
                     v[l] = lds_ld32u(in, valid[l] ? p : 0);
-                    h[l] = lz4_hash(v[l]);
+                    h[l] = lz4_hash<HB>(v[l]);
                     back[l] = lds_ld32u(in, backpos);
                 }
                 nv = popc64(ballot(valid));
@@ -683,7 +688,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             // LZ4 and "read all slots, then write" agree, so the 64-lane collision machinery is not needed:
             // slots in one LDS round trip, candidates in a second, writes only for the probes actually consumed.
             if (!headed && pre && nv >= 4) {
-                FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; }
+                FOR_LANES_W(l) { tab16[lz4_hash<HB>(back[l])] = (uint16_t)backpos; }
                 LV<uint32_t> h1, h2, h3, old4;
                 lane_prev(h, h1);
                 lane_prev(h1, h2);
@@ -735,7 +740,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                 }
                 CIMG_PROF_LAP(7);
             }
-            if (pre) { FOR_LANES_W(l) { tab16[lz4_hash(back[l])] = (uint16_t)backpos; } }
+            if (pre) { FOR_LANES_W(l) { tab16[lz4_hash<HB>(back[l])] = (uint16_t)backpos; } }
             // a lane with the same hash as its left neighbour has that neighbour as candidate
             LV<uint32_t> ph, pv;
             LV<int> ppos;

@@ -847,7 +847,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
         za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize);
         za.dbg = nullptr; za.done = nullptr; za.skipped = nullptr;
         if (za.lds_bytes > e->lds_per_wg) {
-            for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // blocks too large for one workgroup's LDS (> 72 KiB)
+            for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // blocks too large for one workgroup's LDS
         } else {
             if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
             if ((rc = e->launch(CIMG_K_DECODE_ZSTD, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;

@@ -10,7 +10,7 @@
 // (tests/golden/zstd_kat.npz, tests/golden/make_zstd_golden.py).
 //
 // Limits (anything else is ERR_CODEC_SUPPORT / ERR_DATA, never an out-of-range access): regenerated size of a frame <= the
-// caller's capacity, literals of one block <= the work area's lit_cap, no dictionary, window = the frame itself.
+// caller's capacity, no dictionary, window = the frame itself.  The output buffer doubles as the literal buffer (zstd_block).
 #pragma once
 #include "codec_types.h"
 #include "wave.h"
@@ -18,7 +18,7 @@
 
 namespace cimg {
 
-enum : int { ZSTD_LIT_CAP = 65536, ZSTD_HUF_LOG_MAX = 11, ZSTD_FSE_LOG_MAX = 9 };
+enum : int { ZSTD_HUF_LOG_MAX = 11, ZSTD_FSE_LOG_MAX = 9 };
 
 struct ZstdFseEntry { uint8_t sym, nb; uint16_t base; };      // (read as one little-endian dword in the sequence loop)
 static_assert(sizeof(ZstdFseEntry) == 4, "one dword per entry");
@@ -31,8 +31,9 @@ struct ZstdWork {
     uint8_t weights[256];
     int32_t ll_log, ml_log, of_log, huf_log, have_huf, have_tables;
     int32_t rank_count[ZSTD_HUF_LOG_MAX + 2], rank_idx[ZSTD_HUF_LOG_MAX + 2];
-    int32_t lit_cap;         // bytes at lit (<= ZSTD_LIT_CAP)
-    uint8_t* lit;            // literal buffer
+    int32_t tail;            // 1: the frame lies in global memory -- the section being decoded is copied to `stage` when it fits there
+    int32_t stage_cap;       // bytes at stage
+    uint8_t* stage;          // 16-byte aligned
 };
 
 // ---- bit readers --------------------------------------------------------------------------------------------------
@@ -368,6 +369,34 @@ CIMG_DEV void zstd_match(uint8_t* dst, int offset, int n)
     for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = pat[(k0 + l) % offset]; } }
 }
 
+// any alignment on either side, 16 bytes per lane and four loads in flight (dst and src do not overlap)
+CIMG_DEV void zstd_stage(uint8_t* dst, const uint8_t* src, int n)
+{
+    const int head = imin(n, (int)((16 - ((uintptr_t)dst & 15)) & 15));
+    FOR_LANES_W(l) { if (l < head) dst[l] = src[l]; }
+    dst += head; src += head; n -= head;
+    const int units = n >> 4;
+    for (int u0 = 0; u0 < units; u0 += 256) {
+        LV<u128> t0, t1, t2, t3;
+        FOR_LANES(l) {
+            const int u = u0 + l;
+            if (u < units) t0[l] = ld128u(src + 16 * u);
+            if (u + 64 < units) t1[l] = ld128u(src + 16 * (u + 64));
+            if (u + 128 < units) t2[l] = ld128u(src + 16 * (u + 128));
+            if (u + 192 < units) t3[l] = ld128u(src + 16 * (u + 192));
+        }
+        FOR_LANES_W(l) {
+            const int u = u0 + l;
+            if (u < units) st128a(dst + 16 * u, t0[l]);
+            if (u + 64 < units) st128a(dst + 16 * (u + 64), t1[l]);
+            if (u + 128 < units) st128a(dst + 16 * (u + 128), t2[l]);
+            if (u + 192 < units) st128a(dst + 16 * (u + 192), t3[l]);
+        }
+    }
+    const int done = units << 4;
+    FOR_LANES_W(l) { if (done + l < n) dst[done + l] = src[done + l]; }
+}
+
 // ---- one compressed block ---------------------------------------------------------------------------------------------
 struct ZstdFrameState { int r0, r1, r2; };      // the three repeat offsets
 
@@ -388,28 +417,41 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         else if (sf == 2) { hdr = 4; regen = (int)((v >> 4) & 0x3FFF); comp = (int)((v >> 18) & 0x3FFF); streams = 4; }
         else { hdr = 5; regen = (int)((v >> 4) & 0x3FFFF); comp = (int)((v >> 22) & 0x3FFFF); streams = 4; }
     }
-    if (regen > w->lit_cap) return ERR_CODEC_SUPPORT;
+    // The literals of a block have no buffer of their own: they are regenerated at the END of the output, dst[dcap - regen, dcap).
+    // Sequence by sequence they move down to where they belong, and what is written never passes what is still unread: the
+    // output stands at dpos + (literals consumed) + (bytes matched), the unread literals begin at dcap - regen + (literals
+    // consumed), and dpos + regen + (all the block's matches) <= dcap in any frame that fits dst.  (A frame that does not fit
+    // fails the bounds checks below, possibly after garbling literals of its own -- all of it inside dst.)  Copies run in
+    // ascending 64-byte steps, load before store, which is safe for a source AT OR ABOVE its destination.
+    if (regen > dcap - dpos) return ERR_DATA;
+    uint8_t* const litbuf = dst + (dcap - regen);
     int pos = hdr;
-    const uint8_t* lit = w->lit;
+    const uint8_t* lit = litbuf;
+    // A frame in global memory (w->tail): every bit read and every literal run would wait for a load from there, once per
+    // sequence.  Raw literals are brought over in one piece; the coded literals, then the sequences, go through w->stage when
+    // they fit it (they are read where they lie when not).
+    const int stage_cap = w->tail ? w->stage_cap : 0;
     if (ltype == 0) {
         if (pos + regen > size) return ERR_DATA;
-        lit = src + pos;                                   // raw literals are used where they lie
+        if (w->tail) zstd_stage(litbuf, src + pos, regen);
+        else lit = src + pos;                              // raw literals of a frame in LDS are used where they lie
         pos += regen;
     } else if (ltype == 1) {
         if (pos + 1 > size) return ERR_DATA;
-        zstd_fill(w->lit, zstd_u8(src, pos), regen);
+        zstd_fill(litbuf, zstd_u8(src, pos), regen);
         pos += 1;
     } else {
         if (pos + comp > size) return ERR_DATA;
         const uint8_t* ls = src + pos;
         int lsz = comp;
+        if (comp <= stage_cap) { zstd_stage(w->stage, ls, comp); ls = w->stage; }
         if (ltype == 2) {
             const int t = zstd_huf_read_tree(ls, lsz, w);
             if (t < 0) return t;
             ls += t; lsz -= t;
         } else if (!w->have_huf) return ERR_DATA;
         if (streams == 1) {
-            const int rc = zstd_huf_stream(ls, lsz, w->lit, regen, w);
+            const int rc = zstd_huf_stream(ls, lsz, litbuf, regen, w);
             if (rc < 0) return rc;
         } else {
             if (lsz < 6) return ERR_DATA;
@@ -419,7 +461,7 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
             const int per = (regen + 3) / 4;
             if (3 * per > regen) return ERR_DATA;
             if (s1 < 1 || s2 < 1 || s3 < 1) return ERR_DATA;
-            const int rc = zstd_huf_stream4(ls + 6, s1, s2, s3, s4, w->lit, per, regen - 3 * per, w);
+            const int rc = zstd_huf_stream4(ls + 6, s1, s2, s3, s4, litbuf, per, regen - 3 * per, w);
             if (rc < 0) return rc;
         }
         pos += comp;
@@ -464,6 +506,7 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         }
         const uint8_t* bs = src + pos;
         const int bl = size - pos;
+        if (bl >= 1 && bl <= stage_cap) { zstd_stage(w->stage, bs, bl); bs = w->stage; }
         if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
         ZstdBack br;
         br.init(bs, bl, (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1))));

@@ -29,7 +29,7 @@
 namespace cimg {
 
 enum : int { ZSTD_ENC_MAX_INPUT = 65535,         // literal lengths, match lengths and offsets of a stream fit 16 bits
-              ZSTD_ENC_STAGE_END = 16384 - 16 };  // the bit stream is staged inside the 16 KiB of the (dead) hash table, behind the FSE tables
+              ZSTD_ENC_HASH_BITS = 12 };         // the match finder's table: 4096 slots of 16 bits (8 KiB; afterwards the place of the FSE tables)
 
 // FSE compression tables of the three predefined distributions (literal lengths: 36 symbols, log 6; offsets: 29, log 5; match
 // lengths: 53, log 6), built once on the host the way FSE_buildCTable builds them: state table + per symbol (deltaNbBits,
@@ -150,22 +150,23 @@ CIMG_DEV bool zstd_take_parked(const uint8_t* in, cimg_global_u8p lit_out, int l
     return true;
 }
 
-// the bit stream under construction: bits are appended at the low end of a 64-bit container and leave it bytewise into LDS
+// the bit stream under construction: bits are appended at the low end of a 64-bit container and leave it bytewise, straight to
+// their place in the frame (stores nobody waits for; the plane in LDS stays intact for the raw store of a frame that does not pay)
 struct ZstdBitWriter {
-    uint8_t* lds;
-    int pos, limit;          // next byte in LDS, first byte not to be written
+    cimg_global_u8p frame;
+    int pos, limit;          // next byte of the frame, first byte not to be written
     uint64_t cont;
     int nbits;
     bool overflow;
-    CIMG_DEV void init(uint8_t* l, int begin, int end) { lds = l; pos = begin; limit = end; cont = 0; nbits = 0; overflow = false; }
+    CIMG_DEV void init(cimg_global_u8p f, int begin, int end) { frame = f; pos = begin; limit = end; cont = 0; nbits = 0; overflow = false; }
     CIMG_DEV void add(uint32_t value, int n) { cont |= (uint64_t)(value & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u))) << nbits; nbits += n; }
-    // whole bytes of the container -> LDS (at most 7 bits stay); call before the container could pass 64 bits
+    // whole bytes of the container -> frame (at most 7 bits stay); call before the container could pass 64 bits
     CIMG_DEV void flush()
     {
         const int nb = nbits >> 3;
         if (pos + 8 > limit) { overflow = true; return; }
         const uint64_t c = cont;
-        FOR_LANES_W(l) { if (l < nb) lds[pos + l] = (uint8_t)(c >> (8 * (l & 7))); }
+        FOR_LANES_W(l) { if (l < nb) frame[pos + l] = (uint8_t)(c >> (8 * (l & 7))); }
         pos += nb;
         cont = nb >= 8 ? 0 : (cont >> (8 * nb));
         nbits &= 7;
@@ -186,7 +187,7 @@ CIMG_DEV uint32_t zstd_fse_init(const uint16_t* state_table, int dnb, int dfs)
 }
 
 // The frame around what the match finder left: lds = the wave's LDS (plane at 0, n bytes, dead by now; table area at tab_off,
-// 16 KiB, dead too), out = the stream's output (cap bytes; the literal area at out + zstd_frame_prefix(n) is filled already),
+// dead too: the FSE tables' place), out = the stream's output (cap bytes; the literal area at out + zstd_frame_prefix(n) is filled already),
 // sink = the sequences.  Returns the frame size, 0 when it does not fit cap (or is not smaller than n).
 CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p out, int cap, const SeqSink& sink, const ZstdEncTables* tabs_global)
 {
@@ -206,12 +207,8 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
     const int nseq_bytes = nseq < 128 ? 1 : nseq < 0x7F00 ? 2 : 3;
     const int stream_at = seq_at + nseq_bytes + 1;               // the FSE bit stream (behind the symbol-compression-modes byte)
     if (stream_at + 8 >= cap) return 0;
-    // the bit stream is collected in LDS behind the tables (the plane stays intact: a frame that does not pay is followed by a raw
-    // store of the plane); at most cap - stream_at bytes are of any use
-    const int stage = tab_off + (int)((sizeof(ZstdEncTables) + 15) & ~(size_t)15);
-    const int room = imin(cap - stream_at, tab_off + ZSTD_ENC_STAGE_END - stage);
     ZstdBitWriter bw;
-    bw.init(lds, stage, stage + room);
+    bw.init(out, stream_at, cap);
     // ---- FSE: the last sequence first ---------------------------------------------------------------------------------------
     uint32_t st_ll = 0, st_of = 0, st_ml = 0;
     for (int base = ((nseq - 1) >> 6) << 6; base >= 0; base -= 64) {          // batches of 64 records, highest first
@@ -258,10 +255,10 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
     bw.add(1, 1);                                                 // the end mark the decoder looks for
     bw.flush();
     if (bw.overflow) return 0;
-    int stream_bytes = bw.pos - stage;
+    int stream_bytes = bw.pos - stream_at;
     if (bw.nbits > 0) {
         const uint64_t c = bw.cont;
-        FOR_LANES_W(l) { if (l == 0) lds[stage + stream_bytes] = (uint8_t)c; }
+        FOR_LANES_W(l) { if (l == 0) out[stream_at + stream_bytes] = (uint8_t)c; }       // (flush kept eight bytes of room)
         stream_bytes += 1;
     }
     const int total = stream_at + stream_bytes;
@@ -293,8 +290,6 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
             if (v >= 0) out[seq_at + l] = (uint8_t)v;
         }
     }
-    // ---- the bit stream LDS -> frame ---------------------------------------------------------------------------------------
-    for (int c = 0; c < stream_bytes; c += 64) { FOR_LANES(l) { if (c + l < stream_bytes) out[stream_at + c + l] = lds[stage + c + l]; } }
     return total;
 }
 

@@ -1,12 +1,13 @@
 // zstd_kernel.h -- blocks of zstd-coded chunks (blosc2 codec format 4), one wave per block.  The slow path of the decoder:
-// chunks the reference wrote with enums::codec::zstd (enums.h:18-24) stay readable; nothing here is tuned.
+// chunks the reference wrote with enums::codec::zstd (enums.h:18-24) stay readable.
 //
 // The engine launches this kernel only behind a batch in which cimg_decode_blocks reported ERR_CODEC_SUPPORT for some chunk
 // (engine.hip: decompress_finish clears STATUS_ZSTD_PENDING words only).  A block of any other chunk is left alone, whatever
-// its status says.  LDS: the block's streams decoded back to back, the literal buffer
-// of the frame being decoded -- which for streams of half a block or less shares its area with a copy of the frame --, the
-// entropy tables (zstd_decode.h: ZstdWork): 76 KiB, two blocks per CU.  Every lane executes the scalar decoder with the same data (wave-uniform control flow, same-value LDS writes); the
-// filter stage at the end (the general kernel's) and the byte movers are the lane-parallel parts.
+// its status says.  LDS: the block's streams decoded back to back (a frame's literals are regenerated inside its own output:
+// zstd_decode.h, zstd_block), 8 KiB through which the frame -- or, of a larger one, the section being decoded -- is read, the
+// entropy tables (ZstdWork): 52.5 KiB for 32 KiB blocks, three blocks per CU.  The decoder is issue bound (every lane executes
+// the scalar decoder with the same data: wave-uniform control flow, same-value LDS writes), so its rate is the number of waves
+// a CU holds; the filter stage at the end (the general kernel's) and the byte movers are the lane-parallel parts.
 #pragma once
 #include "decode_kernel.h"
 #include "zstd_decode.h"
@@ -14,13 +15,11 @@
 namespace cimg {
 
 // The launch is sized for the largest block of the batch (rounded up to 64 bytes, at least 32 KiB): `area` bytes for the planes,
-// `area` for the literals, then the tables.  160 KiB of LDS hold blocks of up to 72 KiB that way; the kernel reads `area` back
-// from the launch's LDS size.
-enum : int { ZSTD_KERNEL_AREA_MIN = 32768 };
+// 16 bytes nobody uses, the stage, the tables.  The kernel reads `area` back from the launch's LDS size.
+enum : int { ZSTD_KERNEL_AREA_MIN = 32768, ZSTD_KERNEL_STAGE = 8192 };
 CIMG_HD int zstd_work_bytes() { return (int)((sizeof(ZstdWork) + 15) & ~(size_t)15); }
 CIMG_HD int zstd_kernel_area(int max_blocksize) { const int a = (max_blocksize + 63) & ~63; return a < ZSTD_KERNEL_AREA_MIN ? ZSTD_KERNEL_AREA_MIN : a; }
-// the block's planes | the literal buffer (its upper half: a copy of the frame, for streams of half a block or less) | the entropy tables
-CIMG_HD int zstd_kernel_lds_bytes(int max_blocksize) { return 2 * zstd_kernel_area(max_blocksize) + zstd_work_bytes() + 64; }
+CIMG_HD int zstd_kernel_lds_bytes(int max_blocksize) { return zstd_kernel_area(max_blocksize) + 16 + ZSTD_KERNEL_STAGE + zstd_work_bytes() + 64; }
 
 struct DecodeZstdBlock {
     const DecodeArgs& a;
@@ -50,7 +49,7 @@ struct DecodeZstdBlock {
         const int filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE)) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) { fail(chunk, ERR_CODEC_SUPPORT); return; }          // bit rows are never split
-        const int area = ((a.lds_bytes - zstd_work_bytes() - 64) >> 1) & ~63;            // zstd_kernel_lds_bytes, read backwards
+        const int area = (a.lds_bytes - zstd_work_bytes() - 64 - ZSTD_KERNEL_STAGE - 16) & ~63;   // zstd_kernel_lds_bytes, read backwards
         if (area < ZSTD_KERNEL_AREA_MIN || blocksize > area) { fail(chunk, ERR_CODEC_SUPPORT); return; }
         const bool leftover_blk = bsize != blocksize;
         const int ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
@@ -58,14 +57,12 @@ struct DecodeZstdBlock {
         if (cbytes < HEADER_LEN + 4 * d.nblocks) { fail(chunk, ERR_READ_BUFFER); return; }
         const int bstart = ld32s(c + HEADER_LEN + 4 * j);
         if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { fail(chunk, ERR_DATA); return; }
-        ZstdWork* w = reinterpret_cast<ZstdWork*>(lds + 2 * area);
-        // streams of at most half a block (the split planes of a 2- or 4-byte type): the literal buffer needs only half of its
-        // area and the frame is copied into the other half -- the decoder reads it bit by bit, and an LDS read is a fifth of
-        // a global one.  A stream as large as the block keeps the whole literal area; its frame is read where it lies.
-        const bool staged = neblock <= area / 2;
-        uint8_t* stage = lds + area + area / 2;
-        w->lit = lds + area;
-        w->lit_cap = staged ? area / 2 : area;
+        ZstdWork* w = reinterpret_cast<ZstdWork*>(lds + area + 16 + ZSTD_KERNEL_STAGE);
+        // a frame of at most ZSTD_KERNEL_STAGE bytes is copied into LDS whole -- the decoder reads it bit by bit, and an LDS read is
+        // a fifth of a global one; of a larger one, each block's sections go through the same bytes when they fit (ZstdWork::tail)
+        uint8_t* const stage = lds + area + 16;
+        w->stage = stage;
+        w->stage_cap = ZSTD_KERNEL_STAGE;
         int pos = bstart;
         for (int s = 0; s < ns; s++) {
             if (cbytes - pos < 4) { fail(chunk, ERR_READ_BUFFER); return; }
@@ -85,7 +82,9 @@ struct DecodeZstdBlock {
             } else if (cs > neblock) {
                 fail(chunk, ERR_DATA); return;
             } else {
-                if (staged) wave_copy_g2l(c + pos, lds, area + area / 2, cs);   // cs < neblock <= half the area
+                const bool staged = cs <= ZSTD_KERNEL_STAGE;
+                if (staged) wave_copy_g2l(c + pos, lds, area + 16, cs);
+                w->tail = staged ? 0 : 1;
                 const int r = zstd_decode_frame(staged ? stage : c + pos, cs, plane, neblock, w);
                 if (r != neblock) { fail(chunk, r < 0 ? r : ERR_DATA); return; }
             }

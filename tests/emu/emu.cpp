@@ -200,7 +200,7 @@ int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, 
 int emu_zstd_encode(const uint8_t* src, int n, uint8_t* dst, int cap)
 {
     if (n > ZSTD_ENC_MAX_INPUT) return -1;
-    std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
+    std::vector<uint8_t> lds((size_t)encode_lds_bytes(n, CODEC_ZSTD) + EMU_LDS_SLACK, 0xCD);
     memcpy(lds.data(), src, (size_t)n);
     std::vector<uint32_t> seq((size_t)2 * (n / 4 + 64), 0xA5A5A5A5u);
     static ZstdEncTables tabs;
@@ -214,18 +214,28 @@ int emu_zstd_encode(const uint8_t* src, int n, uint8_t* dst, int cap)
     return zstd_finish_frame(lds.data(), round16(n), n, dst, cap, sink, &tabs);
 }
 
-// one zstd frame through csrc/zstd_decode.h (the work area the kernel keeps in LDS is on the heap here)
+// one zstd frame through csrc/zstd_decode.h (the work area the kernel keeps in LDS is on the heap here), the ways the kernel
+// uses it: the frame as a copy the decoder reads in place (tail = 0), and the frame "in global memory" (tail = 1) with a stage
+// like the kernel's and with one so small that most sections are read where they lie.  All must agree; -999 says they did not.
 int emu_zstd_decode(const uint8_t* src, int csize, uint8_t* dst, int cap)
 {
-    std::vector<uint8_t> lit((size_t)ZSTD_LIT_CAP + 64);
-    std::vector<ZstdWork> w(1);
-    w[0].lit = lit.data();
-    w[0].lit_cap = ZSTD_LIT_CAP;
     std::vector<uint8_t> in(src, src + csize);            // exact-size copy: a read past the end is an ASAN finding
-    std::vector<uint8_t> out((size_t)cap);
-    const int rc = zstd_decode_frame(in.data(), csize, out.data(), cap, &w[0]);
-    if (rc > 0) memcpy(dst, out.data(), (size_t)rc);
-    return rc;
+    int rc3[3] = {0, 0, 0};
+    std::vector<uint8_t> out3[3];
+    for (int mode = 0; mode < 3; ++mode) {
+        const int stage_cap = mode == 1 ? (int)ZSTD_KERNEL_STAGE : 96;
+        std::vector<uint8_t> stage((size_t)stage_cap + 16);
+        std::vector<ZstdWork> w(1);
+        w[0].stage = stage.data() + ((16 - ((uintptr_t)stage.data() & 15)) & 15);
+        w[0].stage_cap = stage_cap;
+        w[0].tail = mode ? 1 : 0;
+        out3[mode].assign((size_t)cap, 0);
+        rc3[mode] = zstd_decode_frame(in.data(), csize, out3[mode].data(), cap, &w[0]);
+    }
+    for (int mode = 1; mode < 3; ++mode)
+        if ((rc3[0] >= 0) != (rc3[mode] >= 0) || (rc3[0] >= 0 && (rc3[0] != rc3[mode] || memcmp(out3[0].data(), out3[mode].data(), (size_t)rc3[0])))) return -999;
+    if (rc3[0] > 0) memcpy(dst, out3[0].data(), (size_t)rc3[0]);
+    return rc3[0];
 }
 
 int emu_lz4_decode(const uint8_t* src, int csize, uint8_t* dst, int n)

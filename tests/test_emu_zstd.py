@@ -106,10 +106,10 @@ def test_chunks_made_with_the_local_libzstd(golden_dir):
                 rc, status, out = E.decompress_batch([chunk], [src.size], [32768])
                 assert rc == 0 and status == [0], (dtype, clevel, filt, status)
                 assert out[0].tobytes() == src.tobytes(), (dtype, clevel, filt)
-    # other block sizes: 64 KiB (the kernel's LDS areas follow the batch's largest block), 4 KiB
+    # other block sizes: 128 and 64 KiB (the kernel's LDS follows the batch's largest block; unsplit streams above 64 KiB), 4 KiB
     a = synth.natural_channel(np.uint16, 512, 300)
     src = np.ascontiguousarray(a).view(np.uint8).ravel()
-    for bs in (65536, 4096):
+    for bs in (131072, 65536, 4096):
         for clevel in (3, 9):
             chunk = G.frame(z, src, 2, bs, clevel)
             rc, status, out = E.decompress_batch([chunk], [src.size], [bs])

@@ -830,10 +830,10 @@ def test_zstd_chunks_made_on_this_box(eng, golden_dir):
     assert not status.any()
     for k, (o, w) in enumerate(zip(outs, want)):
         assert o.tobytes() == w.tobytes(), k
-    # other block sizes: 64 KiB (the kernel's LDS areas follow the batch's largest block), 4 KiB
+    # other block sizes: 128 and 64 KiB (the kernel's LDS follows the batch's largest block; unsplit streams above 64 KiB), 4 KiB
     a = synth.natural_channel(np.uint16, 1024, 600)
     src = np.ascontiguousarray(a).view(np.uint8).ravel()
-    for bs in (65536, 4096):
+    for bs in (131072, 65536, 4096):
         chunks = [G.frame(z, src, 2, bs, clevel) for clevel in (3, 9)]
         outs, status = eng.decompress_host(chunks)
         assert not status.any(), bs

@@ -37,7 +37,7 @@ for fam, clevel in (("tiled", 3), ("tiled", 9), ("natural", 3)):
     t0 = time.perf_counter()
     for _ in range(3): eng.decompress_device(d_comp.ptr, coff, nb, [32768] * len(chunks), d_out.ptr, roff)
     wall = (time.perf_counter() - t0) / 3
-    ms, k = eng.kernel_time(3)
+    ms, k = eng.kernel_time(hip.K_DECODE_ZSTD)
     eng.enable_timing(False)
     print("   device-resident: wall %.1f ms per batch; decode kernels %.1f ms per batch over %d timed launches" % (wall * 1e3, ms / 3, k))
     lz = eng.compress_host(hip.cparams(2), host, [chunk] * len(chunks), [chunk + 32] * len(chunks))
