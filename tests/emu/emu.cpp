@@ -233,7 +233,7 @@ int emu_zstd_decode(const uint8_t* src, int csize, uint8_t* dst, int cap)
         rc3[mode] = zstd_decode_frame(in.data(), csize, out3[mode].data(), cap, &w[0]);
     }
     for (int mode = 1; mode < 3; ++mode)
-        if ((rc3[0] >= 0) != (rc3[mode] >= 0) || (rc3[0] >= 0 && (rc3[0] != rc3[mode] || memcmp(out3[0].data(), out3[mode].data(), (size_t)rc3[0])))) return -999;
+        if ((rc3[0] >= 0) != (rc3[mode] >= 0) || (rc3[0] >= 0 && (rc3[0] != rc3[mode] || (rc3[0] > 0 && memcmp(out3[0].data(), out3[mode].data(), (size_t)rc3[0]))))) return -999;
     if (rc3[0] > 0) memcpy(dst, out3[0].data(), (size_t)rc3[0]);
     return rc3[0];
 }
