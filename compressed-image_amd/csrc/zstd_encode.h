@@ -28,7 +28,7 @@
 
 namespace cimg {
 
-enum : int { ZSTD_ENC_MAX_INPUT = 65535,         // literal lengths, match lengths and offsets of a stream fit 16 bits
+enum : int { ZSTD_ENC_MAX_INPUT = 65536,         // a 64 KiB block as one stream: offsets and match lengths stay below 2^16 (a match starts behind a first byte)
               ZSTD_ENC_HASH_BITS = 12 };         // the match finder's table: 4096 slots of 16 bits (8 KiB; afterwards the place of the FSE tables)
 
 // FSE compression tables of the three predefined distributions (literal lengths: 36 symbols, log 6; offsets: 29, log 5; match

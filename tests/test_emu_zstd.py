@@ -173,6 +173,10 @@ def test_zstd_encoder_frames_decode_with_libzstd_and_with_the_own_decoder():
         "period_10": np.tile(np.arange(10, dtype=np.uint8), 20),
         "far_matches_60k": np.tile(rng.integers(0, 256, 3000, dtype=np.uint8), 20)[:60000],
         "max_65535": np.tile(rng.integers(0, 7, 257, dtype=np.uint8), 256)[:65535],
+        "max_65536": np.tile(rng.integers(0, 7, 259, dtype=np.uint8), 256)[:65536],
+        "max_65536_one_match": np.zeros(65536, np.uint8),            # the longest match and, in the mirror case, the longest literal run
+        "max_65536_literals_then_match": np.concatenate([rng.integers(0, 256, 65000, dtype=np.uint8), np.zeros(536, np.uint8)]),
+        "max_65536_far_offset": (lambda head: np.concatenate([head, rng.integers(0, 256, 64936, dtype=np.uint8), head]))(rng.integers(0, 256, 300, dtype=np.uint8)),
         "one_long_literal_run_then_match": np.concatenate([rng.integers(0, 256, 20000, dtype=np.uint8), np.zeros(3000, np.uint8)]),
         "tiny_40": np.zeros(40, np.uint8) + np.arange(40, dtype=np.uint8) % 3,
         "random": rng.integers(0, 256, 16384, dtype=np.uint8),
@@ -238,3 +242,45 @@ def test_zstd_and_lz4hc_chunks_from_the_emulated_kernels():
                 rc, status, outs = E.decompress_batch(chunks, sizes, [O.cbuffer_sizes(c)[2] for c in chunks])
                 assert rc == 0 and not any(status)
                 assert b"".join(o.tobytes() for o in outs) == raw.tobytes()
+
+
+def test_randomized_geometries_zstd_and_lz4hc_on_the_emulated_kernels():
+    """The GPU test of the same name (tests/test_gpu_parity.py) at sizes the lane emulator finishes in seconds: random element size,
+    block size, chunk size, level, filter, dest capacity and data make-up through the emulated encode kernels; the checker
+    (libzstd / the LZ4 block decoder under the oracle's chunk layer) and the emulated decode kernels both return the input."""
+    import _oracle as O
+    from test_gpu_parity import _mixed_data
+    rng = np.random.default_rng(20260304 + int(os.environ.get("CIMG_TEST_SEED", "0")))
+    have_zstd = O.zstd_available()
+    for it in range(int(os.environ.get("CIMG_TEST_ROUNDS", "200"))):
+        codec = O.ZSTD if it % 3 else O.LZ4HC
+        ts = int(rng.choice([1, 2, 2, 4, 4, 8, 3]))
+        blocksize = int(rng.choice([256, 1024, 4096, 8192, 32768, 65536])) // ts * ts
+        nchunks = int(rng.integers(1, 3))
+        chunk = int(rng.integers(1, 4)) * blocksize + (int(rng.integers(0, blocksize)) // ts * ts if rng.random() < 0.4 else 0)
+        chunk = min(chunk, 100000) // ts * ts or ts
+        total = max(chunk * (nchunks - 1) + int(rng.integers(1, chunk + 1)) // ts * ts, ts)
+        raw = _mixed_data(rng, total, ts)
+        clevel = int(rng.choice([1, 5, 9, 9]))
+        filt = int(rng.choice([0, 1, 1, 1, 2]))
+        dest = chunk + 32 if rng.random() < 0.7 else max(40, int(chunk * rng.uniform(0.3, 1.0)))
+        sizes = [min(chunk, total - o) for o in range(0, total, chunk)]
+        what = (it, codec, ts, blocksize, chunk, clevel, filt, dest)
+        rc, cb, chunks = E.compress_batch(E.cparams(ts, clevel=clevel, blocksize=blocksize, compcode=codec, filters=(0, 0, 0, 0, 0, filt)), raw, sizes, [dest] * len(sizes))
+        assert rc == 0, what
+        off = 0
+        live, live_sizes = [], []
+        for c, n in zip(chunks, sizes):
+            if c:
+                if codec == O.LZ4HC or have_zstd:
+                    r, px = O.decompress(c)
+                    assert r == n and px.tobytes() == raw[off:off + n].tobytes(), what
+                if codec == O.LZ4HC:
+                    assert c == O.compress(O.cparams(ts, clevel=clevel, blocksize=blocksize, compcode=O.LZ4HC, filters=(0, 0, 0, 0, 0, filt)), raw[off:off + n], destsize=dest)[1], what
+                live.append((c, n, off))
+            off += n
+        if live:
+            rc, status, outs = E.decompress_batch([c for c, _, _ in live], [n for _, n, _ in live], [O.cbuffer_sizes(c)[2] for c, _, _ in live])
+            assert rc == 0 and not any(status), (what, status)
+            for o, (_, n, at) in zip(outs, live):
+                assert o.tobytes() == raw[at:at + n].tobytes(), what

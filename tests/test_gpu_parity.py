@@ -945,6 +945,51 @@ def test_zstd_and_lz4hc_encoders_write_valid_chunks(eng):
                 print(f"{name} clevel {clevel} {np.dtype(dtype).name} {fam}: ratio {raw.size / sum(map(len, got)):.3f}")
 
 
+def test_randomized_geometries_zstd_and_lz4hc_round_trips(eng):
+    """The write side of the two format-valid codecs over random element size, block size (up to 64 KiB: a zstd stream's limit),
+    chunk size, level (split / unsplit), filter, dest capacity and data make-up: every chunk the GPU writes is decoded (1) by the
+    GPU decoders and (2) by the checker -- libzstd / liblz4's twin under the oracle's chunk layer -- to the input, and equals what
+    the kernel sources write on the host lane emulator (every 8th case: the emulator is slow)."""
+    import _emu as Em
+    rng = np.random.default_rng(20260303 + int(os.environ.get("CIMG_TEST_SEED", "0")))
+    have_zstd = O.zstd_available()
+    for it in range(int(os.environ.get("CIMG_TEST_ROUNDS", "400")) // 2):
+        codec = hip.ZSTD if it % 3 else hip.LZ4HC
+        ts = int(rng.choice([1, 2, 2, 4, 4, 8, 3]))
+        blocksize = int(rng.choice([256, 1024, 4096, 8192, 32768, 65536])) // ts * ts
+        nchunks = int(rng.integers(1, 4))
+        chunk = int(rng.integers(1, 7)) * blocksize + (int(rng.integers(0, blocksize)) // ts * ts if rng.random() < 0.4 else 0)
+        chunk = min(chunk, 300000) // ts * ts or ts
+        total = max(chunk * (nchunks - 1) + int(rng.integers(1, chunk + 1)) // ts * ts, ts)
+        raw = _mixed_data(rng, total, ts)
+        clevel = int(rng.choice([1, 5, 9, 9]))
+        filt = int(rng.choice([0, 1, 1, 1, 2]))
+        dest = chunk + 32 if rng.random() < 0.7 else max(40, int(chunk * rng.uniform(0.3, 1.0)))
+        sizes = [min(chunk, total - o) for o in range(0, total, chunk)]
+        p = hip.cparams(ts, clevel=clevel, blocksize=blocksize, compcode=codec, filters=(0, 0, 0, 0, 0, filt))
+        chunks = eng.compress_host(p, raw, sizes, [dest] * len(sizes))
+        what = (it, codec, ts, blocksize, chunk, clevel, filt, dest)
+        if it % 8 == 0:
+            rc, cb, emu = Em.compress_batch(Em.cparams(ts, clevel=clevel, blocksize=blocksize, compcode=codec, filters=(0, 0, 0, 0, 0, filt)), raw, sizes, [dest] * len(sizes))
+            assert rc == 0 and [c for c in emu] == [c for c in chunks], what
+        off = 0
+        for c, n in zip(chunks, sizes):
+            if c and (codec == hip.LZ4HC or have_zstd):
+                r, px = O.decompress(c)
+                assert r == n and px.tobytes() == raw[off:off + n].tobytes(), what
+            off += n
+        live = [c for c in chunks if c]                                      # (b"": the chunk did not fit dest -- the reference's error)
+        if live:
+            outs, status = eng.decompress_host(live)
+            assert not status.any(), (what, status)
+            off = k = 0
+            for c, n in zip(chunks, sizes):
+                if c:
+                    assert outs[k].tobytes() == raw[off:off + n].tobytes(), what
+                    k += 1
+                off += n
+
+
 @pytest.mark.parametrize("compcode", [hip.LZ4, hip.BLOSCLZ])
 def test_every_combination_of_plane_kinds_decodes_on_the_gpu(eng, compcode):
     """All 9 / 81 combinations of plane kinds (coded / stored / run) of a 32 KiB block of 2- / 4-byte elements, back to back in
