@@ -107,6 +107,13 @@ CIMG_HD bool encode_block_items_ok(int typesize, int filter, int blocksize)
     return (typesize == 2 || typesize == 4) && filter == FILTER_SHUFFLE && blocksize == 32768;
 }
 
+// item time stamps (diagnostics); a -DCIMG_PROFILE build keeps its cycle laps in the same 16 words per item instead
+#if defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
+#define CIMG_ITEM_STAMP(dbg, item, k) ((void)0)
+#else
+#define CIMG_ITEM_STAMP(dbg, item, k) debug_stamp(dbg, item, k)
+#endif
+
 #ifdef CIMG_EMULATE
 extern long g_emu_windows, g_emu_matches, g_emu_collisions;   // test-side statistics only
 #define CIMG_STAT(x) (++(x))
@@ -954,7 +961,7 @@ CIMG_DEV_OUTLINE int encode_account(kernarg_ptr<EncodeArgs> ap_in, int item_in, 
     uint32_t* flag = a->ready + chunk;
     const uint32_t gen = a->gen;
     FOR_LANES_W(l) { if (l == 0) atomic_store_agent(flag, gen); }
-    debug_stamp(a->dbg, item, 1);                            // diagnostics (tools/diag_assemble.py): this item's wave closed a chunk
+    CIMG_ITEM_STAMP(a->dbg, item, 1);                            // diagnostics (tools/diag_assemble.py): this item's wave closed a chunk
     return item;
 }
 
@@ -1014,7 +1021,7 @@ CIMG_DEV_OUTLINE void encode_emit_own(kernarg_ptr<EncodeArgs> ap_in, int last_in
                     if (whole || ns == 1) eb.run_streams(0, ns);
                     else eb.run_streams(s, s + 1);
                     FOR_LANES_W(l) { if (l == 0) next_item[it] = (next + 1) | ITEM_DONE; }
-                    debug_stamp(fresh(ap)->dbg, it, 2);                 // diagnostics: the item's streams are in place
+                    CIMG_ITEM_STAMP(fresh(ap)->dbg, it, 2);                 // diagnostics: the item's streams are in place
                 } else {
                     pending = true;
                 }
@@ -1393,7 +1400,7 @@ struct EncodeStream {
             encode_resident(rec_index, neblock, out, accel_or_level, dbg, item);
         }
 #if !defined(CIMG_PROFILE) && !defined(CIMG_EMULATE)
-        debug_stamp(dbg, item, 3);                                       // item done
+        CIMG_ITEM_STAMP(dbg, item, 3);                                       // item done
 #endif
         return planes;
     }
