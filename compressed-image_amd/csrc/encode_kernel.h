@@ -446,6 +446,8 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     cw[l] = lds_ld32u(in, old0 + 4 * l);
                     iw[l] = lds_ld32u(in, ip0 + 4 * l);
                 }
+                // (without this the compiler moves the loads of scan / before / iw into the branches below: a third round trip)
+                needed_here(scan); needed_here(before); needed_here(iw);
                 const bool hit0 = readlane(cw, 0) == v0;
                 CIMG_STAT(g_emu_matches);
                 if (hit0) {
@@ -714,6 +716,7 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
                     cw[l] = lds_ld32u(in, c0 + 4 + 4 * l);
                     iw[l] = lds_ld32u(in, p0 + 4 + 4 * l);
                 }
+                needed_here(cw); needed_here(iw);                 // (one round trip with the candidates: see run_path)
                 const uint64_t hm = ballot(hit4);
                 if (hm) {
                     const int m4 = ctz64(hm);

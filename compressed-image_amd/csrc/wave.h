@@ -50,6 +50,7 @@ template <class T> struct LV {
     const T& operator[](int l) const { return v[l]; }
 };
 
+template <class T> inline void needed_here(const LV<T>&) {}
 extern int g_emu_write_order;                 // 0 ascending, 1 descending, 2 shuffled
 inline int emu_lane(int i)
 {
@@ -168,6 +169,10 @@ template <class T> struct LV {
 
 #define FOR_LANES(l) for (int l = (int)__lane_id(), l##_once = 1; l##_once; l##_once = 0)
 #define FOR_LANES_W(l) FOR_LANES(l)
+
+// "this value is needed HERE": keeps the compiler from sinking the load that produces x into a branch behind this point, where it
+// would be a dependent LDS round trip of its own instead of sharing one with the loads around it (encode_kernel.h: run_path)
+template <class T> CIMG_DEV void needed_here(const LV<T>& x) { asm volatile("" :: "v"(x.v)); }
 
 CIMG_DEV uint64_t ballot(const LV<bool>& p) { return __ballot(p.v); }
 template <class T> CIMG_DEV T readlane(const LV<T>& x, int lane)
