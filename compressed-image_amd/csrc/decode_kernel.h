@@ -416,21 +416,29 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
                 // lengths need no more bytes, a following token exists
                 good[l] = litok[l] & (!has_ext | (ex[l] < 255)) & (ip + nxt < iend) & (off_l[l] != 0);
             }
-            const uint64_t goodmask = ballot(good);
+            // what the walk reads: the window offset of the next token, or "this is no token the batch can take" (WALK_BAD)
+            enum : int { WALK_BAD = 0x2000 };
+            FOR_LANES(l) { walk_l[l] = good[l] ? walk_l[l] : (int)WALK_BAD; }
             CIMG_PROF_LAP(1);                                   // per-lane header parse
             // the real token chain: a scalar walk over the per-lane "next token" answers
             uint64_t tokens = 0;
             int s = 0;
-            // Straight-line scalar code: one v_readlane, a bit set and two tests per token, unrolled eight times so that the tests
-            // are forward branches that are NOT taken while the chain goes on (a rolled loop pays a taken backward branch, 20
-            // cycles, per token).  24 steps cover the 22 tokens a window can hold.  (Round 2 walked dense windows by pointer
-            // doubling over the LDS crossbar: ~60 instructions but six dependent crossbar round trips; this form is 8 instructions
-            // per token and no round trip.  The two measure the same on the tiled family, this one 4 % better on the natural family.)
-#define CIMG_WALK_STEP if (s >= 64 || !((goodmask >> s) & 1)) break; tokens |= 1ull << s; s = readlane(walk_l, s);
+            // Straight-line scalar code, unrolled eight times so that the tests are forward branches that are NOT taken while the
+            // chain goes on (a rolled loop pays a taken backward branch, 20 cycles, per token).  24 steps cover the 22 tokens a window
+            // can hold.  A step is ONE v_readlane and one compare on the way to the next: the answer of a lane says at once whether
+            // the token counts (round 3's first form tested a bit of a ballot mask first: eight instructions a token, six of them
+            // on the dependent path; this one has three there).  (Round 2 walked dense windows by pointer doubling over the LDS
+            // crossbar: ~60 instructions but six dependent crossbar round trips -- the same time on the tiled family, 4 % worse on
+            // the natural family.)
+            int t_ = 0;                                         // what lane s answered (> 63: the walk ends at s)
+#define CIMG_WALK_STEP t_ = readlane(walk_l, s); if (t_ > 63) break; tokens |= 1ull << s; s = t_;
             for (int rnd = 0; rnd < 3; ++rnd) {
                 CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP
             }
 #undef CIMG_WALK_STEP
+            // the token the walk ended at: it counts unless it is none the batch can take; its answer says where the batch ends
+            // (after 24 steps without an end, s is simply the next token, not taken yet)
+            if (t_ > 63 && !(t_ & WALK_BAD)) { tokens |= 1ull << s; s = t_; }
             int biglast = 0;
             if (s >= 1024) { s -= 1024; biglast = 1; }
             CIMG_PROF_LAP(2);                                   // token chain walk
