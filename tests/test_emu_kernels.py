@@ -234,13 +234,15 @@ def test_unusual_typesizes():
             assert rc == 0 and not any(st) and outs[0].tobytes() == raw.tobytes()
 
 
-def test_randomized_geometries_against_the_oracle():
+@pytest.mark.parametrize("compcode", [1, 0])
+def test_randomized_geometries_against_the_oracle(compcode):
     """The seeded differential test of tests/test_gpu_parity.py on the emulated kernels (fewer rounds), cycling
-    through the three colliding-write orders."""
+    through the three colliding-write orders; lz4 (compcode 1) and blosclz (0, every level)."""
     from test_gpu_parity import _mixed_data
-    rng = np.random.default_rng(20260102)
+    rng = np.random.default_rng(20260102 + compcode)
     for it in range(40):
         ts = int(rng.choice([1, 2, 2, 4, 4, 8, 3]))
+        clevel = 9 if compcode == 1 else int(rng.integers(1, 10))
         blocksize = int(rng.choice([256, 1024, 4096, 8192, 32768])) // ts * ts
         chunk = min(int(rng.integers(1, 6)) * blocksize + (int(rng.integers(0, blocksize)) // ts * ts if rng.random() < 0.4 else 0), 120000) // ts * ts or ts
         total = max(chunk * int(rng.integers(0, 3)) + int(rng.integers(1, chunk + 1)) // ts * ts, ts)
@@ -250,15 +252,15 @@ def test_randomized_geometries_against_the_oracle():
         sizes = [min(chunk, total - o) for o in range(0, total, chunk)]
         E.set_write_order(it % 3)
         try:
-            rc, cb, chunks = E.compress_batch(E.cparams(ts, blocksize=blocksize, filters=(0, 0, 0, 0, 0, filt)), raw, sizes, [dest] * len(sizes))
+            rc, cb, chunks = E.compress_batch(E.cparams(ts, clevel=clevel, blocksize=blocksize, compcode=compcode, filters=(0, 0, 0, 0, 0, filt)), raw, sizes, [dest] * len(sizes))
         finally:
             E.set_write_order(0)
         assert rc == 0
-        po = O.cparams(ts, blocksize=blocksize, filters=(0, 0, 0, 0, 0, filt))
+        po = O.cparams(ts, clevel=clevel, blocksize=blocksize, compcode=compcode, filters=(0, 0, 0, 0, 0, filt))
         off = 0
         for i, s in enumerate(sizes):
             r, want = O.compress(po, raw[off:off + s], destsize=dest)
-            assert cb[i] == r and chunks[i] == want, (it, i, ts, blocksize, chunk, filt, dest)
+            assert cb[i] == r and chunks[i] == want, (compcode, it, i, ts, blocksize, chunk, clevel, filt, dest)
             off += s
         live = [(c, s) for c, s in zip(chunks, sizes) if len(c)]
         if live:
