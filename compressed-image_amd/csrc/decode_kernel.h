@@ -43,7 +43,7 @@ struct DecodeArgs {
     int32_t uniform_nblocks;  // > 0: every chunk has this many blocks (chunk = block / uniform_nblocks)
     uint32_t* done;           // optional, per block: == gen when cimg_decode_lean already wrote the block's pixels
     uint32_t gen;
-    uint32_t* skipped;        // optional (lean launch): counts the blocks it left to the general kernel
+    uint32_t* skipped;        // optional (lean launch): one word per wave of the launch (zeroed by the host), the blocks that wave left to the general kernel
     int32_t total_blocks;     // blocks of the batch (the persistent lean launch strides over them)
 };
 

@@ -64,6 +64,7 @@ struct DecodeLeanWave {
     // registers until the un-shuffle (16 KiB = 16 x 16 bytes per lane): its latency hides behind the decode
     LV<u128> pre[16];
     int prefetched = 0;
+    int left = 0;                        // blocks this wave left to the general kernel (leave())
 
     CIMG_DEV DecodeLeanWave(const DecodeArgs& a_, uint8_t* lds_) : a(a_), lds(lds_) {}
 
@@ -238,10 +239,10 @@ struct DecodeLeanWave {
         return (uint32_t)at[p] * 0x01010101u;
     }
 
-    CIMG_DEV void leave() const
-    {
-        if (a.skipped) { FOR_LANES(l) { if (l == 0) atomic_count(a.skipped); } }
-    }
+    // a block left to the general kernel: counted in a register; the wave reports its count ONCE, with a plain store into its own
+    // word of page-locked host memory (run()).  (Round 2 counted with a system-scope atomic per block on one host address:
+    // a PCIe round trip each, one after the other -- a batch the lean kernel cannot take at all, 4096 blocks, waited 4 ms for them.)
+    CIMG_DEV void leave() { ++left; }
 
     CIMG_DEV void unshuffle(int b)
     {
@@ -378,6 +379,7 @@ struct DecodeLeanWave {
             LEAN_STAMP(a.dbg, b, 3);
             cur = nxt; body = nbody; nxt = far;
         }
+        if (a.skipped && left) { const uint32_t v = (uint32_t)left; FOR_LANES_W(l) { if (l == 0) a.skipped[w] = v; } }
     }
 };
 

@@ -213,6 +213,7 @@ struct cimg_engine {
         bool lean = false, general_now = true, timed = false;
         bool launched = false;            // decompress_launch got as far as enqueueing kernels: decompress_finish has something to wait for
         int32_t nchunks = 0, total_blocks = 0, lds_bytes = 0, max_blocksize = 0;
+        int32_t lean_grid = 0;            // waves of the lean launch = words of its left-over counts behind the status words
         size_t st_bytes = 0;
         DecodeArgs da{};
     } dflight;
@@ -714,6 +715,7 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
 {
     (void)hipSetDevice(e->device);
     e->dflight.launched = false;                  // a rejected batch must not be finished on the previous batch's state
+    e->dflight.lean_grid = 0;
     e->dflight.nchunks = 0;
     e->begin_batch(1);
     DecodePlan plan;
@@ -723,7 +725,8 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
     const size_t st_bytes = sizeof(int32_t) * (size_t)nchunks;
     if ((rc = e->upload_descs(e->descs_dec, e->shadow_dec, e->h_descs_dec, plan.descs.data(), desc_bytes))) return rc;
-    if ((rc = e->reserve(e->h_dec, st_bytes + 32))) return rc;
+    // (behind the status words: one word per wave of the lean launch -- at most a wave per block --, the blocks it left over)
+    if ((rc = e->reserve(e->h_dec, st_bytes + 32 + sizeof(uint32_t) * (size_t)plan.total_blocks))) return rc;
     int32_t* st_dev = nullptr;                    // the status words live in pinned host memory; only failing blocks write
     if ((rc = e->device_alias(e->h_dec, &st_dev))) return rc;
     memset(e->h_dec.p, 0, st_bytes);
@@ -756,7 +759,6 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
         }
         done = (uint32_t*)e->done.p;
         skipped_host = (volatile uint32_t*)((uint8_t*)e->h_dec.p + ((st_bytes + 15) & ~(size_t)15));
-        *skipped_host = 0;
         skipped_dev = (uint32_t*)((uint8_t*)st_dev + ((st_bytes + 15) & ~(size_t)15));
     }
     EventPair ev{};
@@ -782,6 +784,8 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
             // popped per block serialises on its one address (8192 device-scope atomics inside 60 us: 152 against 68 us).
             const int resident = per_cu_use * e->num_cus;
             const int grid = plan.total_blocks > 3 * resident ? plan.total_blocks : std::min(plan.total_blocks, resident);
+            memset((void*)skipped_host, 0, sizeof(uint32_t) * (size_t)grid);        // a wave only writes its word if it left blocks over
+            e->dflight.lean_grid = grid;
             DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, dbg,
                           plan.uniform_nblocks, done, e->done_gen, skipped_dev, plan.total_blocks};
             rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, grid, 64, plan.lds_lean);
@@ -819,7 +823,8 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     int rc;
     if ((rc = cimg_engine_synchronize(e))) return rc;
     if (lean) {
-        const uint32_t skipped = *skipped_host;
+        uint32_t skipped = 0;
+        for (int w = 0; w < f.lean_grid; ++w) skipped += skipped_host[w];
         e->lean_batches++; e->lean_blocks_skipped += skipped; e->lean_blocks_total += plan.total_blocks;
         e->lean_last_skipped = skipped;
         if ((int64_t)skipped * 4 > plan.total_blocks) e->lean_hold = 16;

@@ -131,7 +131,8 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     if (g_emu_lean) {
         // cimg_decode_lean: persistent waves; wave w of G walks blocks w, w + G, ... with the loads of the next two blocks issued
         // ahead (here they simply happen early).  G rotates so that one-, two- and many-block walks are all covered.
-        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr, plan.total_blocks};
+        std::vector<uint32_t> left((size_t)plan.total_blocks + 1, 0);          // one word per wave: the blocks it left to the general kernel
+        DecodeArgs la{plan.descs.data(), nchunks, comp, raw, status, plan.lds_lean, nullptr, plan.uniform_nblocks, done.data(), gen, left.data(), plan.total_blocks};
         std::vector<uint8_t> llds((size_t)plan.lds_lean + EMU_LDS_SLACK);
         static int rot = 0;
         const int choices[4] = {1, 3, 7, plan.total_blocks > 0 ? plan.total_blocks : 1};
@@ -141,7 +142,13 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
             DecodeLeanWave wave(la, llds.data());
             wave.run(w, G);
         }
-        for (int b = 0; b < plan.total_blocks; b++) if (done[(size_t)b] == gen) g_emu_lean_blocks++;
+        int lean_done = 0;
+        for (int b = 0; b < plan.total_blocks; b++) if (done[(size_t)b] == gen) lean_done++;
+        g_emu_lean_blocks += lean_done;
+        // what the host adds up (engine.hip: decompress_finish) is exactly what the lean waves did not decode
+        uint32_t left_sum = 0;
+        for (uint32_t v : left) left_sum += v;
+        if ((int)left_sum != plan.total_blocks - lean_done) return -1;
     }
     DecodeArgs da{plan.descs.data(), nchunks, comp, raw, status, plan.lds_bytes, nullptr, plan.uniform_nblocks, done.data(), gen, nullptr, plan.total_blocks};
     for (int b = 0; b < plan.total_blocks; b++) {
