@@ -375,7 +375,7 @@ struct DecodeLeanWave {
             issue_body(nbody, nxt);                     // ... its size words and coded bytes are requested now
             issue_head(far, b + 2 * G);                 // block i + 2: descriptor, header, bstarts[j]
             if (ok && chain(cur)) unshuffle(b);
-            else leave();
+            else if (!(cur.leftover_blk && a.blk_first)) leave();      // (a.blk_first != 0: the leftover blocks are launched separately, nobody counts them)
             LEAN_STAMP(a.dbg, b, 3);
             cur = nxt; body = nbody; nxt = far;
         }

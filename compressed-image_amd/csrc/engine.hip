@@ -103,7 +103,8 @@ extern "C" __global__ __launch_bounds__(64) void cimg_decode_zstd(DecodeArgs a)
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    DecodeBlock blk(a, lds, (int)blockIdx.x);
+    const int b = a.blk_first + (int)blockIdx.x * a.blk_step;
+    DecodeBlock blk(a, lds, b);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifdef CIMG_PROFILE
     // diagnostic builds: the 16 uint64 per workgroup carry the LZ4 decoder's cycle laps instead of phase stamps
@@ -111,13 +112,13 @@ extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs 
     __syncthreads();
     blk.phase_b(wave);
 #else
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 0);
+    if (wave == 0) debug_stamp(a.dbg, b, 0);
     blk.phase_a(wave);
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 1);       // stream 0 staged
-    if (wave == 1) debug_stamp(a.dbg, (int)blockIdx.x, 2);       // stream 1 staged
+    if (wave == 0) debug_stamp(a.dbg, b, 1);                     // stream 0 staged
+    if (wave == 1) debug_stamp(a.dbg, b, 2);                     // stream 1 staged
     __syncthreads();
     blk.phase_b(wave);
-    if (wave == 0) debug_stamp(a.dbg, (int)blockIdx.x, 3);
+    if (wave == 0) debug_stamp(a.dbg, b, 3);
 #endif
 }
 
@@ -148,6 +149,10 @@ struct cimg_engine {
     // host-buffer calls: pixels / chunks of the NEXT group travel over PCIe (copy streams) while the kernels of the
     // current group run (stream) and the results of the PREVIOUS one travel back
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipStream_t s_side = nullptr;       // the small one of two encode launches of a batch runs here, beside the large one (compress_launch)
+    hipEvent_t ev_side_pre = nullptr, ev_side_done = nullptr;
+    bool stream_has_prelude = false;    // this batch put a copy / memset on `stream` that a launch on another stream has to wait for
+    bool no_side = getenv("CIMG_NO_SIDE_STREAM") != nullptr;   // diagnostic: the two encode launches one behind the other again
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done = nullptr;
     int64_t host_group_bytes = getenv("CIMG_HOST_GROUP_MIB") ? atoll(getenv("CIMG_HOST_GROUP_MIB")) << 20 : 16ll << 20;   // measured: 8 / 16 / 32 / 64 MiB -> 45.9 / 46.6 / 44.3 / 39.0 GB/s
     DevBuf descs_enc, descs_dec, recs, layout, scratch, stage_raw, stage_comp, stage_il, dbg, queue;
@@ -179,7 +184,7 @@ struct cimg_engine {
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
     int64_t zstd_batches = 0;           // decode batches that needed cimg_decode_zstd
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
-    uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over (1: unknown yet -> general kernel enqueued up front)
+    uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over BEYOND the leftover blocks its geometry announced (1: unknown yet -> general kernel enqueued up front)
     int num_cus = 256;
     int enc_waves_cu = 1;               // encode waves per CU the registers allow (occupancy query, cached with enc_wgs_lds)
     int lds_per_cu = 163840, lds_per_wg = 65536;      // device properties
@@ -214,6 +219,7 @@ struct cimg_engine {
         bool launched = false;            // decompress_launch got as far as enqueueing kernels: decompress_finish has something to wait for
         int32_t nchunks = 0, total_blocks = 0, lds_bytes = 0, max_blocksize = 0;
         int32_t lean_grid = 0;            // waves of the lean launch = words of its left-over counts behind the status words
+        int32_t known_left = 0;           // leftover blocks (one per chunk) that the geometry says the lean kernel leaves
         size_t st_bytes = 0;
         DecodeArgs da{};
     } dflight;
@@ -268,6 +274,7 @@ struct cimg_engine {
         // buffer is free again
         if ((rc = hip(hipMemcpyAsync(dev.p, staging.p, bytes, hipMemcpyHostToDevice, stream), "descs H2D"))) return rc;
         shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
+        stream_has_prelude = true;
         return 0;
     }
     int reserve(PinBuf& b, size_t bytes)
@@ -309,18 +316,19 @@ struct cimg_engine {
         pending_extra.clear();
     }
     template <class Args>
-    int launch(int kid, void (*kernel)(Args), const Args& args, int grid, int block, int lds)
+    int launch(int kid, void (*kernel)(Args), const Args& args, int grid, int block, int lds, hipStream_t on = nullptr)
     {
         if (grid <= 0) return 0;
+        if (!on) on = stream;
         EventPair ev{};
-        if (timing) { ev = get_events(); (void)hipEventRecord(ev.a, stream); }
-        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3((unsigned)block), (size_t)lds, stream, args);
+        if (timing) { ev = get_events(); (void)hipEventRecord(ev.a, on); }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3((unsigned)block), (size_t)lds, on, args);
         int rc = hip(hipGetLastError(), cimg_kernel_name(kid));
-        if (timing) { (void)hipEventRecord(ev.b, stream); pending[kid].push_back(ev); }
+        if (timing) { (void)hipEventRecord(ev.b, on); pending[kid].push_back(ev); }
         if (!rc && trace) {             // CIMG_TRACE=1: find the launch that does not come back
             fprintf(stderr, "[cimg] launched %s grid %d block %d lds %d ... ", cimg_kernel_name(kid), grid, block, lds);
             fflush(stderr);
-            rc = hip(hipStreamSynchronize(stream), cimg_kernel_name(kid));
+            rc = hip(hipStreamSynchronize(on), cimg_kernel_name(kid));
             fprintf(stderr, "done (%d)\n", rc);
         }
         return rc;
@@ -397,6 +405,13 @@ int cimg_engine_create(int device, cimg_engine** out)
     e = hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&eng->s_h2d, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&eng->s_d2h, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int least = 0, greatest = 0;                // (the small launch should win a tie for the dispatcher)
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&eng->s_side, hipStreamNonBlocking, greatest);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&eng->ev_side_pre, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&eng->ev_side_done, hipEventDisableTiming);
     for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&eng->ev_h2d[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&eng->ev_done, hipEventDisableTiming);
     if (e != hipSuccess) { g_create_error = hipGetErrorString(e); delete eng; return ERR_FAILURE; }
@@ -418,6 +433,9 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamDestroy(e->stream);
     if (e->s_h2d) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamDestroy(e->s_h2d); }
     if (e->s_d2h) { (void)hipStreamSynchronize(e->s_d2h); (void)hipStreamDestroy(e->s_d2h); }
+    if (e->s_side) { (void)hipStreamSynchronize(e->s_side); (void)hipStreamDestroy(e->s_side); }
+    if (e->ev_side_pre) (void)hipEventDestroy(e->ev_side_pre);
+    if (e->ev_side_done) (void)hipEventDestroy(e->ev_side_done);
     for (int k = 0; k < 2; k++) if (e->ev_h2d[k]) (void)hipEventDestroy(e->ev_h2d[k]);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     delete e;
@@ -514,9 +532,12 @@ static HostCParams to_host(const cimg_cparams* p)
 }
 
 // the kernels of one compress batch, enqueued on the engine's stream; compress_finish() waits and fetches the sizes
+// inputs_behind_stream: the pixels are produced by work already enqueued on e->stream (a copy the stream waits for, the
+// deinterleave kernel): a launch on another stream has to wait for that too.  The device-resident entry points pass false --
+// their caller's pixels are there when the call is made.
 static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunks,
                            const void* d_raw, const int64_t* raw_off, const int32_t* nbytes,
-                           void* d_comp, const int64_t* comp_off, const int32_t* destsize)
+                           void* d_comp, const int64_t* comp_off, const int32_t* destsize, bool inputs_behind_stream = true)
 {
     (void)hipSetDevice(e->device);
     e->claunched = false;
@@ -539,6 +560,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     if (!fold) for (ChunkDesc& d : plan.descs) d.assemble = 0;
     for (const ChunkDesc& d : plan.descs) if (!d.assemble) leftovers = true;
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
+    e->stream_has_prelude = inputs_behind_stream;
     if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, e->h_descs, plan.descs.data(), desc_bytes))) return rc;
     const size_t sync_words = 16 + 2 * (size_t)nchunks;
     if (sync_words * 4 > e->sync.cap || (size_t)nchunks > e->sync_chunks) e->sync_dirty = true;
@@ -546,6 +568,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     for (int k = 0; k < 2; k++) if (e->qbase[k] > 0x70000000u) e->sync_dirty = true;
     if (++e->fold_gen == 0) { e->fold_gen = 1; e->sync_dirty = true; }
     if (e->sync_dirty) {
+        e->stream_has_prelude = true;
         if ((rc = e->hip(hipMemsetAsync(e->sync.p, 0, e->sync.cap, e->stream), "sync memset"))) return rc;
         e->qbase[0] = e->qbase[1] = 0;
         e->sync_chunks = (e->sync.cap / 4 - 16) / 2;
@@ -555,9 +578,27 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     e->claunched = true;                          // from here on kernels may be in flight and h_out is this batch's
     e->sync_dirty = true;                         // until the launches below are all enqueued: an error in between leaves the counters unknown
 
-    for (int split = 1; split >= 0; split--) {
+    // Two launches in a batch -- the byte planes of the full blocks, and the unsplit leftover block that every chunk of an image
+    // has whose row size does not divide 4 MiB (c-blosc2 never splits a chunk's last, shorter block) -- do not wait for each other:
+    // the small one goes FIRST, on a stream of its own, and the large one's persistent chains start beside it (its work queue
+    // absorbs the few CUs that come free a little later).  One behind the other the small launch cost a whole item's latency at
+    // the end of the batch (configs[1]'s pixels in chunks of 4 MiB + 4 KiB: 471 us a batch, of which 60 for 31 leftover blocks).
+    // The launches share nothing but read-only inputs: queue heads, item lists and scratch slots are per launch / per block.
+    const bool side = plan.lds_split && plan.lds_unsplit && !e->no_side && plan.cp.compcode != CODEC_ZSTD;   // (zstd: both launches would grow one sequence buffer)
+    // (In the steady state -- same geometry as the batch before -- nothing of this batch is on the main stream yet, and the small
+    // launch is enqueued, and resident, before the host has even prepared the large one.  It only waits when descriptors were
+    // uploaded or counters cleared for this batch.)
+    if (side && e->stream_has_prelude) {
+        if ((rc = e->hip(hipEventRecord(e->ev_side_pre, e->stream), "event record"))) return rc;          // descriptors uploaded, counters cleared
+        if ((rc = e->hip(hipStreamWaitEvent(e->s_side, e->ev_side_pre, 0), "stream wait"))) return rc;
+    }
+    size_t next_item_used = 0;                        // (the launches of a batch get regions of their own in next_item)
+    if ((rc = e->reserve(e->next_item, sizeof(int32_t) * ((size_t)plan.total_blocks * (size_t)(plan.cp.streams_per_block + 1) + 64)))) return rc;
+    for (int pass = 0; pass < 2; pass++) {
+        const int split = side ? pass : 1 - pass;     // side by side: the small (unsplit) launch first
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;                     // no blocks of that kind in the batch
+        hipStream_t const on = (side && !split) ? e->s_side : e->stream;
         // Split launch: whole blocks as work items -- each block read from HBM ONCE instead of once per byte plane -- when
         // the geometry allows it AND the batch is large.  A block item is `typesize` times coarser than a plane item, and
         // on a small batch the coarser granularity costs more than the second read saves (HBM is a few per cent utilised;
@@ -588,12 +629,13 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         uint32_t* const sync = (uint32_t*)e->sync.p;
         uint32_t* head = sync + (split ? 0 : 4);
         const size_t nslots = e->sync_chunks;
-        if ((rc = e->reserve(e->next_item, sizeof(int32_t) * (size_t)items + 64))) return rc;
+        int32_t* const next_item = (int32_t*)e->next_item.p + next_item_used;
+        next_item_used += (size_t)items + 16;
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks,
                       nullptr, 0, nullptr,
                       e->qbase[split], 0, fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
-                      sync + 16, sync + 16 + nslots, (int32_t*)e->next_item.p, e->fold_gen};
+                      sync + 16, sync + 16 + nslots, next_item, e->fold_gen};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ, zst = plan.cp.compcode == CODEC_ZSTD;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : zst ? cimg_encode_streams_zstd : cimg_encode_streams;
         const int lds_slot = blz ? 3 : zst ? 4 : 0;
@@ -643,10 +685,16 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             ea.zstd_seq = (uint32_t*)e->zstd_seq.p; ea.zstd_seq_stride = stride; ea.zstd_tables = (const ZstdEncTables*)e->zstd_tables.p;
         }
         ea.nwaves = grid * gang;
-        if ((rc = e->launch(zst ? CIMG_K_ENCODE_ZSTD : CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes))) return rc;
+        if ((rc = e->launch(zst ? CIMG_K_ENCODE_ZSTD : CIMG_K_ENCODE, enc_kernel, ea, grid, 64 * gang, gang * lds_bytes, on))) return rc;
+        if (side && !split) {
+            // everything that follows on the main stream behind the large launch -- the assembly kernels, the host's wait -- also
+            // waits for the small one
+            if ((rc = e->hip(hipEventRecord(e->ev_side_done, e->s_side), "event record"))) return rc;
+        }
         // the queue deals out the items behind the first nwaves, and every wave pops exactly one past the end
         e->qbase[split] += (uint32_t)(items - std::min(items, ea.nwaves)) + (uint32_t)ea.nwaves;
     }
+    if (side && (rc = e->hip(hipStreamWaitEvent(e->stream, e->ev_side_done, 0), "stream wait"))) return rc;
     if (leftovers) {
         AssembleArgs aa{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (const uint8_t*)e->scratch.p,
                         (const StreamRec*)e->recs.p, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, plan.uniform_nblocks, lay_host, 1};
@@ -679,7 +727,8 @@ int cimg_compress_batch_device(cimg_engine* e, const cimg_cparams* p, int32_t nc
     if (nchunks <= 0) return 0;
     if (!p || !raw_off || !nbytes || !comp_off || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
     e->cflight_chunks = -1;
-    const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize);
+    // (pixels a decode batch of this engine is still writing -- begun, not fetched -- are "behind the stream")
+    const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize, e->dflight_open);
     return rc ? rc : compress_finish(e, nchunks, cbytes);
 }
 
@@ -691,7 +740,7 @@ int cimg_compress_batch_device_begin(cimg_engine* e, const cimg_cparams* p, int3
     e->cflight_chunks = -1;
     if (nchunks <= 0) { e->cflight_chunks = 0; return 0; }
     if (!p || !raw_off || !nbytes || !comp_off || !destsize) return e->fail(ERR_INVALID_PARAM, "null argument");
-    const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize);
+    const int rc = compress_launch(e, p, nchunks, d_raw, raw_off, nbytes, d_comp, comp_off, destsize, e->dflight_open);
     if (!rc) e->cflight_chunks = nchunks;
     return rc;
 }
@@ -711,7 +760,7 @@ int cimg_compress_batch_device_fetch(cimg_engine* e, int32_t nchunks, int32_t* c
 // kernel late if the lean one left blocks behind, and collects the status words
 static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp, const int64_t* comp_off,
                              const int32_t* nbytes, const int32_t* blocksize, void* d_raw, const int64_t* raw_off,
-                             const int32_t* comp_size = nullptr)
+                             const int32_t* comp_size = nullptr, bool inputs_behind_stream = true)
 {
     (void)hipSetDevice(e->device);
     e->dflight.launched = false;                  // a rejected batch must not be finished on the previous batch's state
@@ -761,6 +810,16 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
         skipped_host = (volatile uint32_t*)((uint8_t*)e->h_dec.p + ((st_bytes + 15) & ~(size_t)15));
         skipped_dev = (uint32_t*)((uint8_t*)st_dev + ((st_bytes + 15) & ~(size_t)15));
     }
+    // What the lean kernel leaves by GEOMETRY is known up front: the leftover (last, shorter, never split) block of every chunk
+    // -- one per chunk for every image whose row size does not divide 4 MiB.  In a uniform batch those are blocks nblocks - 1,
+    // 2 nblocks - 1, ...: the general kernel is launched over exactly them (one workgroup per chunk instead of one per block),
+    // and the lean kernel does not count them among the blocks it reports as left over.
+    int known_left = 0;
+    if (lean && plan.uniform_nblocks > 0) {
+        bool all = true;
+        for (const ChunkDesc& d : plan.descs) if (!d.leftover) { all = false; break; }
+        if (all) known_left = nchunks;
+    }
     EventPair ev{};
     const bool timed = e->timing;
     if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
@@ -787,7 +846,7 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
             memset((void*)skipped_host, 0, sizeof(uint32_t) * (size_t)grid);        // a wave only writes its word if it left blocks over
             e->dflight.lean_grid = grid;
             DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, dbg,
-                          plan.uniform_nblocks, done, e->done_gen, skipped_dev, plan.total_blocks};
+                          plan.uniform_nblocks, done, e->done_gen, skipped_dev, plan.total_blocks, known_left ? 1 : 0, 1};   // (blk_first here: leftover blocks are not counted)
             rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, grid, 64, plan.lds_lean);
         }
     }
@@ -796,13 +855,25 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     const bool general_now = !lean || e->lean_last_skipped != 0;
     // (diagnostic stamps go to the lean launch when there is one: both would write the same slots)
     DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, (lean && stamping) ? nullptr : dbg,
-                  plan.uniform_nblocks, done, e->done_gen, nullptr, plan.total_blocks};
+                  plan.uniform_nblocks, done, e->done_gen, nullptr, plan.total_blocks, 0, 1};
     if (!rc && general_now) {
         if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);
+    } else if (!rc && known_left) {
+        // (beside the lean launch, on the side stream, when the chunks are there already: its few workgroups find room as the lean
+        // launch's waves retire -- behind it on the same stream they would run alone on an idle, clocked-down device)
+        const bool beside = !inputs_behind_stream && !e->no_side && !timed;
+        DecodeArgs dk = da;
+        dk.blk_first = plan.uniform_nblocks - 1; dk.blk_step = plan.uniform_nblocks;
+        if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
+            rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, dk, nchunks, 256, plan.lds_bytes, beside ? e->s_side : e->stream);
+        if (!rc && beside) {
+            if (!(rc = e->hip(hipEventRecord(e->ev_side_done, e->s_side), "event record")))
+                rc = e->hip(hipStreamWaitEvent(e->stream, e->ev_side_done, 0), "stream wait");
+        }
     }
     if (timed) { e->timing = true; (void)hipEventRecord(ev.b, e->stream); e->pending[CIMG_K_DECODE].push_back(ev); }
-    e->dflight.lean = lean; e->dflight.general_now = general_now; e->dflight.timed = timed;
+    e->dflight.lean = lean; e->dflight.general_now = general_now; e->dflight.timed = timed; e->dflight.known_left = known_left;
     e->dflight.nchunks = nchunks; e->dflight.total_blocks = plan.total_blocks; e->dflight.lds_bytes = plan.lds_bytes;
     e->dflight.st_bytes = st_bytes; e->dflight.da = da;
     e->dflight.max_blocksize = 0;
@@ -825,7 +896,9 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     if (lean) {
         uint32_t skipped = 0;
         for (int w = 0; w < f.lean_grid; ++w) skipped += skipped_host[w];
-        e->lean_batches++; e->lean_blocks_skipped += skipped; e->lean_blocks_total += plan.total_blocks;
+        // (leftover blocks the geometry announced are not in this count: the general kernel has decoded them already, launched
+        // over every block or over exactly them -- what counts here is what the lean kernel left BEYOND those)
+        e->lean_batches++; e->lean_blocks_skipped += skipped + (uint32_t)f.known_left; e->lean_blocks_total += plan.total_blocks;
         e->lean_last_skipped = skipped;
         if ((int64_t)skipped * 4 > plan.total_blocks) e->lean_hold = 16;
         if (e->verbose) fprintf(stderr, "[cimg] decode: lean kernel left %u of %d blocks to the general kernel%s\n", skipped, plan.total_blocks,
@@ -884,7 +957,8 @@ int cimg_decompress_batch_device_sized(cimg_engine* e, int32_t nchunks, const vo
     if (nchunks <= 0) return 0;
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
     e->dflight_open = false;
-    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, comp_size);
+    // (chunks a compress batch of this engine is still writing -- begun, not fetched -- are "behind the stream")
+    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, comp_size, e->cflight_chunks >= 0);
     if (rc) { if (e->dflight.launched) (void)cimg_engine_synchronize(e); return rc; }
     return decompress_finish(e, status);
 }
@@ -903,7 +977,7 @@ int cimg_decompress_batch_device_begin_sized(cimg_engine* e, int32_t nchunks, co
     e->dflight.nchunks = 0;
     if (nchunks <= 0) { e->dflight_open = true; return 0; }
     if (!comp_off || !nbytes || !blocksize || !raw_off) return e->fail(ERR_INVALID_PARAM, "null argument");
-    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, comp_size);
+    const int rc = decompress_launch(e, nchunks, d_comp, comp_off, nbytes, blocksize, d_raw, raw_off, comp_size, e->cflight_chunks >= 0);
     if (!rc) e->dflight_open = true;
     else if (e->dflight.launched) (void)cimg_engine_synchronize(e);
     return rc;

@@ -951,6 +951,32 @@ def test_zstd_and_lz4hc_encoders_write_valid_chunks(eng):
                 print(f"{name} clevel {clevel} {np.dtype(dtype).name} {fam}: ratio {raw.size / sum(map(len, got)):.3f}")
 
 
+def test_leftover_blocks_of_a_uniform_batch_have_a_launch_of_their_own(eng):
+    """Chunk sizes that are no multiple of the block size (every image whose row size does not divide 4 MiB): the last block of
+    every chunk is shorter and never split, the lean decode kernel leaves it, and from the second such batch on the general kernel
+    is launched over exactly those blocks.  Decoded several times in a row (the launch shape follows the previous batch), then
+    with chunks whose blocks the lean kernel cannot take for their CONTENT (both planes coded: the late full launch), then again."""
+    chunk = 7 * 32768 + 9000                                              # seven full blocks + a leftover
+    tiled = np.ascontiguousarray(synth.tiled_channel(np.float16, 1024, 400)).view(np.uint8).ravel()
+    natural = np.ascontiguousarray(synth.natural_channel(np.float16, 1024, 400)).view(np.uint8).ravel()
+    def batch(raw, n):
+        sizes = [chunk] * n
+        chunks = eng.compress_host(hip.cparams(2), raw[:chunk * n], sizes, [chunk + 32] * n)
+        for i, c in enumerate(chunks):
+            assert c == O.compress(O.cparams(2), raw[i * chunk:(i + 1) * chunk], destsize=chunk + 32)[1]
+        return chunks, raw[:chunk * n]
+    t_chunks, t_raw = batch(tiled, 3)
+    n_chunks, n_raw = batch(natural, 3)
+    mixed = [t_chunks[0], n_chunks[1], t_chunks[2]]
+    mixed_raw = np.concatenate([t_raw[:chunk], n_raw[chunk:2 * chunk], t_raw[2 * chunk:3 * chunk]])
+    for chunks, raw in ((t_chunks, t_raw), (t_chunks, t_raw), (t_chunks, t_raw), (n_chunks, n_raw), (t_chunks, t_raw), (mixed, mixed_raw), (mixed, mixed_raw),
+                        (t_chunks, t_raw), (t_chunks, t_raw)):
+        outs, status = eng.decompress_host(chunks)
+        assert not status.any()
+        got = b"".join(o.tobytes() for o in outs)
+        assert got == raw.tobytes()
+
+
 def test_randomized_geometries_zstd_and_lz4hc_round_trips(eng):
     """The write side of the two format-valid codecs over random element size, block size (up to 64 KiB: a zstd stream's limit),
     chunk size, level (split / unsplit), filter, dest capacity and data make-up: every chunk the GPU writes is decoded (1) by the
