@@ -977,6 +977,31 @@ def test_leftover_blocks_of_a_uniform_batch_have_a_launch_of_their_own(eng):
         assert got == raw.tobytes()
 
 
+def test_leftover_blocks_device_resident_side_by_side(eng):
+    """The same geometry through the device-resident calls, several batches in a row: from the second one on nothing of a batch
+    is on the engine's stream before its launches, so the leftover blocks' launch is enqueued on the side stream without waiting
+    for anything (engine.hip: compress_launch) and runs beside the large one.  Bytes against the oracle every time; lz4 and
+    blosclz; then decoded (leftover blocks: the general kernel over exactly them, beside the lean launch)."""
+    chunk = 31 * 32768 + 31744                                            # a 1920-pixel float16 row size would give 127 + 31744
+    nchunks = 12
+    raws = [np.ascontiguousarray(f(np.float16, 1024, chunk * nchunks // 2048 + 1)).view(np.uint8).ravel()[:chunk * nchunks] for f in (synth.tiled_channel, synth.natural_channel)]
+    stride = (chunk + 32 + 63) // 64 * 64
+    d_raw, d_comp, d_out = eng.alloc(chunk * nchunks), eng.alloc(stride * nchunks), eng.alloc(chunk * nchunks)
+    raw_off = np.arange(nchunks, dtype=np.int64) * chunk
+    comp_off = np.arange(nchunks, dtype=np.int64) * stride
+    for compcode in (hip.LZ4, hip.BLOSCLZ):
+        for raw in raws:
+            d_raw.upload(raw)
+            want = [O.compress(O.cparams(2, compcode=compcode), raw[i * chunk:(i + 1) * chunk], destsize=chunk + 32)[1] for i in range(nchunks)]
+            for rep in range(4):
+                cb = eng.compress_device(hip.cparams(2, compcode=compcode), d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+                blob = d_comp.download(stride * nchunks)
+                for i in range(nchunks):
+                    assert cb[i] == len(want[i]) and blob[i * stride:i * stride + cb[i]].tobytes() == want[i], (compcode, rep, i)
+                eng.decompress_device(d_comp.ptr, comp_off, [chunk] * nchunks, [32768] * nchunks, d_out.ptr, raw_off)
+                assert d_out.download(chunk * nchunks).tobytes() == raw.tobytes(), (compcode, rep)
+
+
 def test_randomized_geometries_zstd_and_lz4hc_round_trips(eng):
     """The write side of the two format-valid codecs over random element size, block size (up to 64 KiB: a zstd stream's limit),
     chunk size, level (split / unsplit), filter, dest capacity and data make-up: every chunk the GPU writes is decoded (1) by the
