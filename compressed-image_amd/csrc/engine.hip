@@ -152,6 +152,7 @@ struct cimg_engine {
     hipStream_t s_side = nullptr;       // the small one of two encode launches of a batch runs here, beside the large one (compress_launch)
     hipEvent_t ev_side_pre = nullptr, ev_side_done = nullptr;
     bool stream_has_prelude = false;    // this batch put a copy / memset on `stream` that a launch on another stream has to wait for
+    bool side_always_waits = getenv("CIMG_SIDE_ALWAYS_WAITS") != nullptr;   // diagnostic: the side launch waits for the main stream even when it need not
     bool no_side = getenv("CIMG_NO_SIDE_STREAM") != nullptr;   // diagnostic: the two encode launches one behind the other again
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done = nullptr;
     int64_t host_group_bytes = getenv("CIMG_HOST_GROUP_MIB") ? atoll(getenv("CIMG_HOST_GROUP_MIB")) << 20 : 16ll << 20;   // measured: 8 / 16 / 32 / 64 MiB -> 45.9 / 46.6 / 44.3 / 39.0 GB/s
@@ -560,7 +561,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     if (!fold) for (ChunkDesc& d : plan.descs) d.assemble = 0;
     for (const ChunkDesc& d : plan.descs) if (!d.assemble) leftovers = true;
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
-    e->stream_has_prelude = inputs_behind_stream;
+    e->stream_has_prelude = inputs_behind_stream || e->side_always_waits;
     if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, e->h_descs, plan.descs.data(), desc_bytes))) return rc;
     const size_t sync_words = 16 + 2 * (size_t)nchunks;
     if (sync_words * 4 > e->sync.cap || (size_t)nchunks > e->sync_chunks) e->sync_dirty = true;
