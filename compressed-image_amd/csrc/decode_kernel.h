@@ -45,9 +45,9 @@ struct DecodeArgs {
     uint32_t gen;
     uint32_t* skipped;        // optional (lean launch): one word per wave of the launch (zeroed by the host), the blocks that wave left to the general kernel
     int32_t total_blocks;     // blocks of the batch (the persistent lean launch strides over them)
-    // cimg_decode_blocks: workgroup k decodes block blk_first + k * blk_step (0, 1: every block; nblocks - 1, nblocks: the last
-    // block of every chunk of a uniform batch -- the leftover blocks the lean kernel never takes).  cimg_decode_lean: blk_first != 0
-    // says that launch exists, and leftover blocks are then not counted in `skipped`.
+    // cimg_decode_blocks: workgroup k decodes block blk_first + k * blk_step (0, 1: every block); blk_step == 0: the LAST block of
+    // chunk k -- the leftover blocks the lean kernel never takes, one workgroup per chunk.  cimg_decode_lean: blk_first != 0 says
+    // that launch exists, and leftover blocks are then not counted in `skipped`.
     int32_t blk_first, blk_step;
 };
 

@@ -103,7 +103,9 @@ extern "C" __global__ __launch_bounds__(64) void cimg_decode_zstd(DecodeArgs a)
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int b = a.blk_first + (int)blockIdx.x * a.blk_step;
+    // (blk_step == 0: workgroup k takes the LAST block of chunk k -- the leftover blocks of a batch, whatever its chunk sizes)
+    const int b = a.blk_step ? a.blk_first + (int)blockIdx.x * a.blk_step
+                             : __builtin_amdgcn_readfirstlane(a.descs[blockIdx.x].blk0 + a.descs[blockIdx.x].nblocks - 1);
     DecodeBlock blk(a, lds, b);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifdef CIMG_PROFILE
@@ -812,15 +814,11 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
         skipped_dev = (uint32_t*)((uint8_t*)st_dev + ((st_bytes + 15) & ~(size_t)15));
     }
     // What the lean kernel leaves by GEOMETRY is known up front: the leftover (last, shorter, never split) block of every chunk
-    // -- one per chunk for every image whose row size does not divide 4 MiB.  In a uniform batch those are blocks nblocks - 1,
-    // 2 nblocks - 1, ...: the general kernel is launched over exactly them (one workgroup per chunk instead of one per block),
-    // and the lean kernel does not count them among the blocks it reports as left over.
+    // -- one per chunk for every image whose row size does not divide 4 MiB.  The general kernel is launched over exactly them
+    // (one workgroup per chunk instead of one per block), and the lean kernel does not count them among the blocks it reports
+    // as left over.
     int known_left = 0;
-    if (lean && plan.uniform_nblocks > 0) {
-        bool all = true;
-        for (const ChunkDesc& d : plan.descs) if (!d.leftover) { all = false; break; }
-        if (all) known_left = nchunks;
-    }
+    if (lean) for (const ChunkDesc& d : plan.descs) if (d.leftover && !d.memcpyed) known_left++;
     EventPair ev{};
     const bool timed = e->timing;
     if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
@@ -865,7 +863,7 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
         // launch's waves retire -- behind it on the same stream they would run alone on an idle, clocked-down device)
         const bool beside = !inputs_behind_stream && !e->no_side && !timed;
         DecodeArgs dk = da;
-        dk.blk_first = plan.uniform_nblocks - 1; dk.blk_step = plan.uniform_nblocks;
+        dk.blk_first = 0; dk.blk_step = 0;                  // workgroup k: the last block of chunk k (a chunk without a leftover block: done already)
         if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, dk, nchunks, 256, plan.lds_bytes, beside ? e->s_side : e->stream);
         if (!rc && beside) {

@@ -951,7 +951,7 @@ def test_zstd_and_lz4hc_encoders_write_valid_chunks(eng):
                 print(f"{name} clevel {clevel} {np.dtype(dtype).name} {fam}: ratio {raw.size / sum(map(len, got)):.3f}")
 
 
-def test_leftover_blocks_of_a_uniform_batch_have_a_launch_of_their_own(eng):
+def test_leftover_blocks_have_a_launch_of_their_own(eng):
     """Chunk sizes that are no multiple of the block size (every image whose row size does not divide 4 MiB): the last block of
     every chunk is shorter and never split, the lean decode kernel leaves it, and from the second such batch on the general kernel
     is launched over exactly those blocks.  Decoded several times in a row (the launch shape follows the previous batch), then
@@ -969,8 +969,15 @@ def test_leftover_blocks_of_a_uniform_batch_have_a_launch_of_their_own(eng):
     n_chunks, n_raw = batch(natural, 3)
     mixed = [t_chunks[0], n_chunks[1], t_chunks[2]]
     mixed_raw = np.concatenate([t_raw[:chunk], n_raw[chunk:2 * chunk], t_raw[2 * chunk:3 * chunk]])
+    # chunks of different sizes in one batch (an image's remainder chunks), one of them without a leftover block
+    sizes = [chunk, 3 * 32768 + 100, 4 * 32768, 2 * 32768 + 30000]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    ragged_raw = tiled[:offs[-1]]
+    ragged = eng.compress_host(hip.cparams(2), ragged_raw, sizes, [s + 32 for s in sizes])
+    for i, c in enumerate(ragged):
+        assert c == O.compress(O.cparams(2), ragged_raw[offs[i]:offs[i + 1]], destsize=sizes[i] + 32)[1]
     for chunks, raw in ((t_chunks, t_raw), (t_chunks, t_raw), (t_chunks, t_raw), (n_chunks, n_raw), (t_chunks, t_raw), (mixed, mixed_raw), (mixed, mixed_raw),
-                        (t_chunks, t_raw), (t_chunks, t_raw)):
+                        (t_chunks, t_raw), (t_chunks, t_raw), (ragged, ragged_raw), (ragged, ragged_raw), (ragged, ragged_raw), (n_chunks, n_raw), (ragged, ragged_raw)):
         outs, status = eng.decompress_host(chunks)
         assert not status.any()
         got = b"".join(o.tobytes() for o in outs)
