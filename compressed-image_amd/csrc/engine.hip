@@ -412,6 +412,7 @@ int cimg_engine_create(int device, cimg_engine** out)
         int least = 0, greatest = 0;                // (the small launch should win a tie for the dispatcher)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         e = hipStreamCreateWithPriority(&eng->s_side, hipStreamNonBlocking, greatest);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&eng->s_side, hipStreamNonBlocking); }   // (no priorities here: an ordinary stream does)
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&eng->ev_side_pre, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&eng->ev_side_done, hipEventDisableTiming);
