@@ -196,6 +196,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
     // ONE way out of both loops (`break` with `ending` set): a return inside a loop makes the compiler dispatch every
     // iteration on an exit selector (encode_kernel.h has the measurement)
     int ending = 1;                                                   // 1: go on; 0: give up (stored raw); < 0: a loop guard tripped
+    bool saw_hit = false;                                             // a probe met four equal bytes somewhere (a candidate that compared equal)
     for (; pass < 3; ++pass) {
         const bool probe = pass < 2;
         if (pass == 2) {
@@ -265,6 +266,7 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
             const uint64_t hits = ballot(hit) & below;
             int m = -1;
             if (hits) {
+                saw_hit = true;
                 // a 4-byte hit is a match only if it is long enough: the next 12 bytes decide every rule
                 LV<bool> acc;
                 FOR_LANES(l) {
@@ -332,6 +334,10 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
             oc += Lc + (t >> 5);
             if ((t & 31) == 0) oc--;
             if (pass == 0) csize3 = oc; else csize4 = oc;
+            // The second probe of level 9 differs from the first only in what it does WITH a hit (the position it goes on from, the
+            // length rule).  A first probe that never met four equal bytes -- the noisy low planes of an image -- is the second
+            // one too: same table, same positions, same count.
+            if (pass == 0 && !saw_hit) { csize4 = csize3; pass = 1; }
         }
     }
     if (ending <= 0) return ending;
