@@ -13,7 +13,7 @@ nchunks, stride = n // chunk, chunk + 64
 d_raw, d_comp = eng.alloc(n), eng.alloc(nchunks * stride)
 d_raw.upload(host)
 raw_off = np.arange(nchunks) * chunk; comp_off = np.arange(nchunks) * stride
-p = hip.cparams(2)
+p = hip.cparams(2, compcode=int(os.environ.get("CIMG_DIAG_CODEC", "1")))
 for _ in range(3):
     eng.compress_device(p, d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
 eng.debug_stamps(True)
