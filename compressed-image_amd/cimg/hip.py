@@ -13,7 +13,11 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("CIMG_LIB") or os.path.join(_PKG, "libcimg_hip.so")   # CIMG_LIB: diagnostic builds
 
 K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE, K_DEINTERLEAVE, K_DECODE_ZSTD, K_ENCODE_ZSTD = 0, 1, 2, 3, 4, 5, 6
-KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks")   # the decode entry times cimg_decode_lean + cimg_decode_blocks together
+# names by timing id (cimg_kernel_name).  K_ENCODE times whichever of cimg_encode_streams / _blosclz the codec selects; K_DECODE
+# times the pair cimg_decode_lean + cimg_decode_blocks (the second only runs for blocks the first left): bench.py reports it under
+# the kernel that did the work
+KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks", "cimg_deinterleave",
+           "cimg_decode_zstd", "cimg_encode_streams_zstd")
 BLOSCLZ, LZ4, LZ4HC, ZLIB, ZSTD = 0, 1, 2, 4, 5
 NOFILTER, SHUFFLE, BITSHUFFLE = 0, 1, 2
 MAX_OVERHEAD = 32
@@ -28,7 +32,7 @@ EXPORTS = (
     "cimg_compress_batch_device_begin", "cimg_compress_batch_device_fetch", "cimg_decompress_batch_device_begin", "cimg_decompress_batch_device_fetch",
     "cimg_decompress_batch_device_sized", "cimg_decompress_batch_device_begin_sized",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
-    "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_kernel_name",
+    "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_engine_kernel_samples", "cimg_engine_decode_stats", "cimg_kernel_name",
     "cimg_engine_debug_stamps", "cimg_engine_read_stamps", "cimg_shared_engine", "cimg_context_cparams",
     # include/blosc2.h
     "blosc2_create_cctx", "blosc2_create_dctx", "blosc2_free_ctx", "blosc2_compress_ctx",
@@ -109,6 +113,9 @@ def load():
     L.cimg_engine_enable_timing.argtypes = [vp, C.c_int]
     L.cimg_engine_reset_timing.argtypes = [vp]
     L.cimg_engine_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.cimg_engine_kernel_samples.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.cimg_engine_decode_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.cimg_engine_decode_stats.restype = None
     L.cimg_kernel_name.argtypes = [C.c_int]
     L.cimg_kernel_name.restype = C.c_char_p
     L.cimg_engine_debug_stamps.argtypes = [vp, C.c_int]
@@ -346,6 +353,19 @@ class Engine:
         ms, n = C.c_double(0), C.c_int64(0)
         self._check(load().cimg_engine_kernel_time(self.handle, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_samples(self, kernel, max_samples=65536):
+        """milliseconds of every timed launch of `kernel` since reset_timing(), oldest first"""
+        out = np.zeros(max_samples, np.float32)
+        n = load().cimg_engine_kernel_samples(self.handle, kernel, _ptr(out), max_samples)
+        if n < 0:
+            self._check(n)
+        return out[:n].copy()
+
+    def decode_stats(self):
+        a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        load().cimg_engine_decode_stats(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return {"lean_batches": a.value, "blocks_left_to_general": b.value, "blocks_total": c.value, "zstd_batches": d.value}
 
 
 def cbuffer_sizes(chunk):

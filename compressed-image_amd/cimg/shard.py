@@ -98,3 +98,58 @@ def gather_chunks(dist, world, rank, local_idx, local_buf, local_off, sizes_all,
         return whole, offsets, sizes_all.copy()
     host = whole.cpu().numpy()
     return [host[int(offsets[g]):int(offsets[g]) + int(sizes_all[g])].copy() for g in range(n_items)]
+
+
+def scatter_chunks(dist, world, rank, whole, offsets, sizes_all, n_items, src=0, items_per_group=1, device="cpu"):
+    """The decode mirror of gather_chunks ("decode is the mirror -- scatter compressed"): rank `src` holds every
+    chunk of an image (packed or not: chunk g at offsets[g], sizes_all[g] bytes of `whole`) and every owner receives ITS chunks,
+    back to back, to decompress them with its own engine.
+
+    sizes_all   int64[n_items], known to every rank (the table of compressed sizes travels first: broadcast_sizes below, or the
+                result of gather_sizes when the chunks were compressed by the same job)
+    whole / offsets are only read on `src`.  Point to point with exact sizes, as in gather_chunks: `src` posts one send per
+    owner rank, every other rank one receive (one RCCL group over the direct xGMI links under "nccl"; one-to-all, nothing padded).
+    Returns on every rank (packed uint8 tensor on `device` holding this rank's chunks, int64 local offsets[len(mine)], the global
+    indices `mine`): chunk mine[k] lies at local_offsets[k], sizes_all[mine[k]] bytes.
+    """
+    import torch
+    sizes_all = np.asarray(sizes_all, dtype=np.int64)
+    owners = [partition(n_items, world, r, items_per_group) for r in range(world)]
+    totals = [int(sizes_all[o].sum()) for o in owners]
+    mine = owners[rank]
+    local_off = np.concatenate([[0], np.cumsum(sizes_all[mine][:-1])]).astype(np.int64) if len(mine) else np.zeros(0, np.int64)
+    multi = dist is not None and dist.is_initialized() and world > 1
+    packs = None
+    if rank == src:
+        if not torch.is_tensor(whole):
+            whole = torch.as_tensor(np.ascontiguousarray(whole).view(np.uint8))
+        offsets = np.asarray(offsets, dtype=np.int64)
+        packs = []
+        for r in range(world):
+            pieces = [whole[int(offsets[g]):int(offsets[g]) + int(sizes_all[g])] for g in owners[r]]
+            packs.append((torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.uint8)).to(device))
+        got = packs[src]
+    else:
+        got = torch.empty(totals[rank], dtype=torch.uint8, device=device)
+    if multi:
+        ops = []
+        if rank == src:
+            ops = [dist.P2POp(dist.isend, packs[r], r) for r in range(world) if r != src and totals[r] > 0]
+        elif totals[rank] > 0:
+            ops = [dist.P2POp(dist.irecv, got, src)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+    assert got.numel() == totals[rank]
+    return got, local_off, mine
+
+
+def broadcast_sizes(dist, sizes, n_items, src=0, device="cpu"):
+    """Every rank learns the compressed size of every chunk that rank `src` holds (int64[n_items]): one broadcast."""
+    import torch
+    t = torch.zeros(n_items, dtype=torch.int64, device=device)
+    if sizes is not None:
+        t[:] = torch.as_tensor(np.asarray(sizes, dtype=np.int64), device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t.cpu().numpy()

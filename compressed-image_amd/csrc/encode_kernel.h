@@ -52,7 +52,7 @@ struct EncodeArgs {
     int32_t total_blocks;
     int32_t want_split;       // 1: this launch encodes the planes of split blocks, 0: unsplit blocks
     uint64_t* dbg;            // diagnostics only: per-item time stamps (nullptr in production)
-    uint32_t* queue;          // work-queue head, zeroed before the launch
+    uint32_t* queue;          // work queue: ENC_NQ heads, ENC_QSTRIDE words apart, zero at launch (see "the work queue" below)
     int32_t uniform_nblocks;  // > 0: every chunk has this many blocks
     int32_t block_items;      // split launch only: the first `block_items` blocks are handed out WHOLE -- read from HBM once, the
                               // byte planes encoded one after the other by the same wave (the planes that wait sit in registers);
@@ -61,8 +61,9 @@ struct EncodeArgs {
     uint32_t* zstd_seq;       // wave w owns zstd_seq + w * zstd_seq_stride (dwords)
     int32_t zstd_seq_stride;
     const ZstdEncTables* zstd_tables;
-    uint32_t queue_base;      // the queue head counts on from batch to batch: item = pop - queue_base + nwaves (nothing resets it in between)
-    int32_t nwaves;           // waves of the launch: wave w takes item w first, the queue deals out the items behind those
+    uint32_t* queue_next;     // the heads the NEXT launch of this kind will use: wave 0 zeroes them (the launches of one kind follow
+                              // each other in stream order, so nobody reads them while this launch runs)
+    int32_t nwaves;           // waves of the launch
     // ---- chunks assembled INSIDE the launch (assemble != 0; round 3) ---------------------------------------------------------
     // A wave remembers the items it encoded (a linked list through next_item[]); the wave that finishes the last stream of a
     // chunk lays the chunk out (LayoutChunk: bstarts, header, the running-destsize rule) and raises ready[chunk]; when the work
@@ -80,6 +81,19 @@ struct EncodeArgs {
     int32_t* next_item;       // per item of this launch: the item the same wave encoded before it (-1: none)
     uint32_t gen;
 };
+
+// ---- the work queue (round 4) -------------------------------------------------------------------------------------------------
+// Items are dealt out by atomic counters.  Device-scope atomics on ONE address are served one after the other (about 10 ns each), so
+// a launch whose 1280 waves all pop one head at t = 0 starts its last chain 13 us late.  Round 3 therefore gave wave w item w without
+// asking -- which made the launch depend on every workgroup being resident: with chunks assembled inside the launch a wave that is
+// out of work WAITS for its chunks to close, i.e. also for first items of workgroups that have not started, and when another
+// persistent launch holds their CUs (a second engine, a second process on the card) that is a deadlock.
+// Now EVERY item is popped -- an item always belongs to a running wave, so a launch completes with any number of resident waves --
+// from ENC_NQ heads on separate cache lines: item i sits in sub-queue i mod ENC_NQ, wave w pops sub-queue w mod ENC_NQ (20 waves
+// per head: 0.2 us of serialisation instead of 13) and, once that is dry, looks at all heads with ONE vector load and pops the next
+// sub-queue that still has items.  Sub-queues advance at about the same pace, so the order of the item list (whole blocks, then
+// coded planes, then noise planes) holds approximately.  Pops past the end are harmless: each launch zeroes the heads of the next.
+enum : int { ENC_NQ = 64, ENC_QSTRIDE = 32 };
 
 enum : int { LZ4_HASH_BYTES = 16384, LZ4_MAX_INPUT_U16 = 65536 + 11 - 1 };
 
@@ -1036,6 +1050,44 @@ CIMG_DEV_OUTLINE void encode_emit_own(kernarg_ptr<EncodeArgs> ap_in, int last_in
     if (pending) { FOR_LANES_W(l) { if (l == 0 && aa.layout_host) aa.layout_host[aa.nchunks].cbytes = -1; } }
 }
 
+// the next item of the launch for wave w, or -1 when every sub-queue is dry ("the work queue" at the top of this file).  Out of line:
+// it runs once per work item, and its vector loads must not count against the codec loop's registers.
+CIMG_DEV_OUTLINE int encode_pop_item(uint32_t* heads_in, int items_in, int w_in)
+{
+    uint32_t* const heads = reinterpret_cast<uint32_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(heads_in)));
+    const int items = uni(items_in), w = uni(w_in);
+    const int myq = w & (ENC_NQ - 1);
+    {
+        const int cnt = (items - myq + ENC_NQ - 1) / ENC_NQ;             // items of sub-queue myq (<= 0: none)
+        LV<uint32_t> got;
+        FOR_LANES(l) { got[l] = 0; }
+        FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(heads + myq * ENC_QSTRIDE); }
+        const uint32_t v = uni(readlane(got, 0));
+        if ((int64_t)v < (int64_t)cnt) return myq + ENC_NQ * (int)v;
+    }
+    // its own sub-queue is dry: look at all heads (one vector load), take from the next one that still has items
+    for (int tries = 0; tries < ENC_NQ; ++tries) {
+        LV<uint32_t> h;
+        LV<bool> has;
+        FOR_LANES(l) {
+            h[l] = atomic_load_agent(heads + l * ENC_QSTRIDE);
+            const int cnt_l = (items - l + ENC_NQ - 1) / ENC_NQ;
+            has[l] = (int64_t)h[l] < (int64_t)cnt_l;
+        }
+        const uint64_t m = ballot(has);
+        if (!m) return -1;
+        const uint64_t behind = myq < 63 ? m >> (myq + 1) << (myq + 1) : 0;   // the thieves spread: each starts behind its own sub-queue
+        const int q = ctz64(behind ? behind : m);
+        const int cnt = (items - q + ENC_NQ - 1) / ENC_NQ;
+        LV<uint32_t> got;
+        FOR_LANES(l) { got[l] = 0; }
+        FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(heads + q * ENC_QSTRIDE); }
+        const uint32_t v = uni(readlane(got, 0));
+        if ((int64_t)v < (int64_t)cnt) return q + ENC_NQ * (int)v;
+    }
+    return -1;
+}
+
 // one single-wave workgroup = one stream.  CODEC selects the stream codec at compile time: the two encoders live in
 // two kernels (merged into one, the scalar state of both pushed the LZ4 kernel from 38 to 84 spilled SGPRs)
 template <int CODEC>
@@ -1255,37 +1307,27 @@ struct EncodeStream {
         }
     }
 
-    // persistent workgroup: pull items until the queue is dry (EVERY wave pops exactly one item past the end: the host counts on
-    // that when it moves queue_base on), then -- when the batch is assembled in place -- copy blocks of finished chunks
+    // persistent workgroup: pull items until the queue is dry, then -- when the batch is assembled in place -- copy this wave's own
+    // streams into place as their chunks close
     CIMG_DEV void run()
     {
-        int items, assemble, nwaves;
+        int items, assemble;
         uint32_t* queue;
-        uint32_t qbase;
         {
             const auto a = fresh(ap);
             items = encode_items(a->total_blocks, a->p.streams_per_block, a->want_split != 0, a->block_items);
             queue = a->queue;
-            qbase = a->queue_base;
             assemble = a->assemble;
-            nwaves = a->nwaves;
+            if (w == 0 && a->queue_next) {                       // the heads of the next launch of this kind
+                uint32_t* const nx = a->queue_next;
+                FOR_LANES_W(l) { atomic_store_agent(nx + l * ENC_QSTRIDE, 0u); }
+            }
         }
-        // The FIRST item of wave w is item w, without asking: device-scope atomics on one address are served one after the other
-        // (about 10 ns each, measured on the decode side), so a launch whose 1280 waves all pop at once starts its last chain
-        // 13 us late.  The queue hands out the items from nwaves on.
-        // bounded: a workgroup can never pop more than every item plus its final empty-queue pop
+        // bounded: a wave can never pop more than every item plus its final empty-queue pop
         int last = -1;                                           // the items this wave encoded, newest first (next_item[])
         for (int pops = 0; pops <= items + 1; ++pops) {
-            int item;
-            if (pops == 0 && w < items) {
-                item = w;
-            } else {
-                LV<uint32_t> got;
-                FOR_LANES(l) { got[l] = 0; }
-                FOR_LANES_W(l) { if (l == 0) got[l] = queue_pop(queue); }
-                item = uni((int)(readlane(got, 0) - qbase)) + nwaves;
-                if (item >= items || item < nwaves) break;
-            }
+            const int item = uni(encode_pop_item(queue, items, w));
+            if (item < 0) break;
             int chunk = 0;
             const int finished = run_item(item, chunk);
             if (assemble && finished > 0) last = encode_account(ap, item, last, chunk, finished);

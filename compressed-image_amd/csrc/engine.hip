@@ -153,8 +153,7 @@ struct cimg_engine {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipStream_t s_side = nullptr;       // the small one of two encode launches of a batch runs here, beside the large one (compress_launch)
     hipEvent_t ev_side_pre = nullptr, ev_side_done = nullptr;
-    bool stream_has_prelude = false;    // this batch put a copy / memset on `stream` that a launch on another stream has to wait for
-    bool side_always_waits = getenv("CIMG_SIDE_ALWAYS_WAITS") != nullptr;   // diagnostic: the side launch waits for the main stream even when it need not
+    bool side_used = false;             // something was launched on s_side since the last synchronize (an error path must not leave it running)
     bool no_side = getenv("CIMG_NO_SIDE_STREAM") != nullptr;   // diagnostic: the two encode launches one behind the other again
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done = nullptr;
     int64_t host_group_bytes = getenv("CIMG_HOST_GROUP_MIB") ? atoll(getenv("CIMG_HOST_GROUP_MIB")) << 20 : 16ll << 20;   // measured: 8 / 16 / 32 / 64 MiB -> 45.9 / 46.6 / 44.3 / 39.0 GB/s
@@ -169,12 +168,13 @@ struct cimg_engine {
     // one batch at a time per engine: the calls share the stream, the staging buffers and the result area.
     // (recursive: the host-buffer calls run the device calls inside)
     std::recursive_mutex mu;
-    // The encode launch's work-queue heads count on from batch to batch; the host keeps the value each starts a launch at.
-    // `sync` holds: words 0 / 4 the queue heads of the split / unsplit launch, then per chunk the count of finished streams, then
-    // per chunk the generation at which the chunk was last laid out inside a launch.  Zeroed when it is (re)allocated, when a
-    // counter nears wrap-around and after any failed batch (sync_dirty).
-    DevBuf sync, next_item, zstd_seq, zstd_tables;   // (zstd encoder: per-wave sequence records, FSE tables of the predefined distributions)
-    uint32_t qbase[2] = {0, 0}, fold_gen = 0;
+    // `qheads`: the encode launches' work-queue heads -- per kind of launch (split / unsplit) two sets of ENC_NQ heads; a launch pops
+    // one set and zeroes the other for the next launch of its kind (encode_kernel.h, "the work queue").
+    // `sync` holds (behind 16 unused words): per chunk the count of finished streams, then per chunk the generation at which the
+    // chunk was last laid out inside a launch.  Both are zeroed when (re)allocated, when the generation wraps and after any
+    // failed batch (sync_dirty).
+    DevBuf sync, next_item, qheads, zstd_seq, zstd_tables;   // (zstd encoder: per-wave sequence records, FSE tables of the predefined distributions)
+    uint32_t qpar[2] = {0, 0}, fold_gen = 0;   // qpar: which of its two sets of queue heads the next split / unsplit launch pops
     bool sync_dirty = true;
     size_t sync_chunks = 0;             // chunks the current layout of `sync` was made for
     bool no_fold = getenv("CIMG_NO_ASSEMBLE_IN_LAUNCH") != nullptr;   // diagnostic: cimg_layout_chunks / cimg_emit_blocks behind every encode launch
@@ -213,6 +213,7 @@ struct cimg_engine {
     std::vector<EventPair> pending[CIMG_K_COUNT];
     std::vector<EventPair> pending_extra;   // late general decode launches: time counts towards CIMG_K_DECODE, launches do not
     std::vector<EventPair> free_events;
+    std::vector<float> samples[CIMG_K_COUNT];   // every timed launch since the last reset (medians: cimg_engine_kernel_samples)
     double total_ms[CIMG_K_COUNT] = {};
     int64_t launches[CIMG_K_COUNT] = {};
     std::string err;
@@ -277,7 +278,6 @@ struct cimg_engine {
         // buffer is free again
         if ((rc = hip(hipMemcpyAsync(dev.p, staging.p, bytes, hipMemcpyHostToDevice, stream), "descs H2D"))) return rc;
         shadow.assign((const uint8_t*)src, (const uint8_t*)src + bytes);
-        stream_has_prelude = true;
         return 0;
     }
     int reserve(PinBuf& b, size_t bytes)
@@ -288,6 +288,15 @@ struct cimg_engine {
         int rc = hip(hipHostMalloc(&b.p, want, hipHostMallocDefault), "hipHostMalloc");
         if (rc) return rc;
         b.cap = want;
+        return 0;
+    }
+    // a launch on the side stream is ordered behind everything `stream` holds now
+    int side_follows_stream()
+    {
+        int rc;
+        if ((rc = hip(hipEventRecord(ev_side_pre, stream), "event record"))) return rc;
+        if ((rc = hip(hipStreamWaitEvent(s_side, ev_side_pre, 0), "stream wait"))) return rc;
+        side_used = true;
         return 0;
     }
     EventPair get_events()
@@ -306,6 +315,7 @@ struct cimg_engine {
                 if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
                     total_ms[k] += ms;
                     launches[k] += 1;
+                    if (samples[k].size() < 65536) samples[k].push_back(ms);
                 }
                 free_events.push_back(ev);
             }
@@ -359,7 +369,7 @@ const char* cimg_kernel_name(int k)
     case CIMG_K_DECODE: return "cimg_decode_blocks";
     case CIMG_K_DEINTERLEAVE: return "cimg_deinterleave";
     case CIMG_K_DECODE_ZSTD: return "cimg_decode_zstd";
-    case CIMG_K_ENCODE_ZSTD: return "cimg_encode_zstd";
+    case CIMG_K_ENCODE_ZSTD: return "cimg_encode_streams_zstd";
     default: return "?";
     }
 }
@@ -430,7 +440,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item, &e->zstd_seq, &e->zstd_tables})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item, &e->qheads, &e->zstd_seq, &e->zstd_tables})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_descs_dec, &e->h_out, &e->h_dec})
         if (b->p) (void)hipHostFree(b->p);
@@ -447,7 +457,17 @@ void cimg_engine_destroy(cimg_engine* e)
 
 const char* cimg_last_error(const cimg_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 void* cimg_engine_stream(cimg_engine* e) { return (void*)e->stream; }
+static int engine_synchronize_main(cimg_engine* e);
 int cimg_engine_synchronize(cimg_engine* e)
+{
+    // (every side launch is joined into the main stream by an event when all goes well; after an error in between it may not be)
+    int rc_side = 0;
+    if (e->side_used) { rc_side = e->hip(hipStreamSynchronize(e->s_side), "hipStreamSynchronize(side)"); e->side_used = false; }
+    const int rc = engine_synchronize_main(e);
+    if (rc || rc_side) e->sync_dirty = true;        // a failed wait: the encode launches' counters are not where the host thinks
+    return rc ? rc : rc_side;
+}
+static int engine_synchronize_main(cimg_engine* e)
 {
     if (!e->spin_sync) return e->hip(hipStreamSynchronize(e->stream), "hipStreamSynchronize");
     // a batch is a few hundred microseconds of kernels: poll an event instead of sleeping on the stream
@@ -501,7 +521,7 @@ void cimg_engine_reset_timing(cimg_engine* e)
 {
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
-    for (int k = 0; k < CIMG_K_COUNT; k++) { e->total_ms[k] = 0; e->launches[k] = 0; }
+    for (int k = 0; k < CIMG_K_COUNT; k++) { e->total_ms[k] = 0; e->launches[k] = 0; e->samples[k].clear(); }
 }
 int cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_t* launches)
 {
@@ -512,6 +532,24 @@ int cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_
     if (total_ms) *total_ms = e->total_ms[kernel];
     if (launches) *launches = e->launches[kernel];
     return 0;
+}
+
+int cimg_engine_kernel_samples(cimg_engine* e, int kernel, float* ms, int max_samples)
+{
+    if (kernel < 0 || kernel >= CIMG_K_COUNT || max_samples < 0) return ERR_INVALID_PARAM;
+    int rc = cimg_engine_synchronize(e);
+    if (rc) return rc;
+    e->drain_timing();
+    const int n = std::min((int)e->samples[kernel].size(), max_samples);
+    if (ms && n) memcpy(ms, e->samples[kernel].data(), sizeof(float) * (size_t)n);
+    return n;
+}
+void cimg_engine_decode_stats(cimg_engine* e, int64_t* lean_batches, int64_t* blocks_left_to_general, int64_t* blocks_total, int64_t* zstd_batches)
+{
+    if (lean_batches) *lean_batches = e->lean_batches;
+    if (blocks_left_to_general) *blocks_left_to_general = e->lean_blocks_skipped;
+    if (blocks_total) *blocks_total = e->lean_blocks_total;
+    if (zstd_batches) *zstd_batches = e->zstd_batches;
 }
 
 // diagnostics: per-workgroup {shader clock, 100 MHz clock, HW_ID, XCC_ID} x {start, end} of the most recent
@@ -564,17 +602,20 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     if (!fold) for (ChunkDesc& d : plan.descs) d.assemble = 0;
     for (const ChunkDesc& d : plan.descs) if (!d.assemble) leftovers = true;
     const size_t desc_bytes = sizeof(ChunkDesc) * (size_t)nchunks;
-    e->stream_has_prelude = inputs_behind_stream || e->side_always_waits;
     if ((rc = e->upload_descs(e->descs_enc, e->shadow_enc, e->h_descs, plan.descs.data(), desc_bytes))) return rc;
     const size_t sync_words = 16 + 2 * (size_t)nchunks;
     if (sync_words * 4 > e->sync.cap || (size_t)nchunks > e->sync_chunks) e->sync_dirty = true;
     if ((rc = e->reserve(e->sync, sync_words * 4))) return rc;
-    for (int k = 0; k < 2; k++) if (e->qbase[k] > 0x70000000u) e->sync_dirty = true;
     if (++e->fold_gen == 0) { e->fold_gen = 1; e->sync_dirty = true; }
+    // the encode launches' work-queue heads (encode_kernel.h, "the work queue"): per kind of launch (split / unsplit) two sets of
+    // ENC_NQ heads; a launch pops one set and zeroes the other for the next launch of its kind
+    const size_t qset_bytes = (size_t)ENC_NQ * ENC_QSTRIDE * 4;
+    if (4 * qset_bytes > e->qheads.cap) e->sync_dirty = true;
+    if ((rc = e->reserve(e->qheads, 4 * qset_bytes))) return rc;
     if (e->sync_dirty) {
-        e->stream_has_prelude = true;
+        if ((rc = e->hip(hipMemsetAsync(e->qheads.p, 0, e->qheads.cap, e->stream), "queue heads memset"))) return rc;
         if ((rc = e->hip(hipMemsetAsync(e->sync.p, 0, e->sync.cap, e->stream), "sync memset"))) return rc;
-        e->qbase[0] = e->qbase[1] = 0;
+        e->qpar[0] = e->qpar[1] = 0;
         e->sync_chunks = (e->sync.cap / 4 - 16) / 2;
         e->sync_dirty = false;
     }
@@ -589,13 +630,13 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     // the end of the batch (configs[1]'s pixels in chunks of 4 MiB + 4 KiB: 471 us a batch, of which 60 for 31 leftover blocks).
     // The launches share nothing but read-only inputs: queue heads, item lists and scratch slots are per launch / per block.
     const bool side = plan.lds_split && plan.lds_unsplit && !e->no_side && plan.cp.compcode != CODEC_ZSTD;   // (zstd: both launches would grow one sequence buffer)
-    // (In the steady state -- same geometry as the batch before -- nothing of this batch is on the main stream yet, and the small
-    // launch is enqueued, and resident, before the host has even prepared the large one.  It only waits when descriptors were
-    // uploaded or counters cleared for this batch.)
-    if (side && e->stream_has_prelude) {
-        if ((rc = e->hip(hipEventRecord(e->ev_side_pre, e->stream), "event record"))) return rc;          // descriptors uploaded, counters cleared
-        if ((rc = e->hip(hipStreamWaitEvent(e->s_side, e->ev_side_pre, 0), "stream wait"))) return rc;
-    }
+    // The small launch is ordered behind everything the engine's stream holds at this point -- descriptors uploaded or counters
+    // cleared for this batch, and ANY producer of the pixels enqueued there before this call (cimg_deinterleave_device, a caller's
+    // own kernel on cimg_engine_stream(), a decode batch begun and not fetched): the stream's contract is "in order", and a launch
+    // that leaves it must not break that.  (Round 3 skipped the wait when this batch itself had put nothing on the stream: an
+    // image deinterleaved on the device and compressed right behind it had its leftover blocks encoded from planes that were not
+    // written yet.)  With an idle stream -- the steady state of a synchronous caller -- the event is complete when it is recorded.
+    if (side && (rc = e->side_follows_stream())) return rc;
     size_t next_item_used = 0;                        // (the launches of a batch get regions of their own in next_item)
     if ((rc = e->reserve(e->next_item, sizeof(int32_t) * ((size_t)plan.total_blocks * (size_t)(plan.cp.streams_per_block + 1) + 64)))) return rc;
     for (int pass = 0; pass < 2; pass++) {
@@ -631,14 +672,16 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             e->dbg_count[0] = items;
         }
         uint32_t* const sync = (uint32_t*)e->sync.p;
-        uint32_t* head = sync + (split ? 0 : 4);
+        uint32_t* const qsets = (uint32_t*)e->qheads.p + (size_t)(split ? 0 : 2) * ENC_NQ * ENC_QSTRIDE;
+        uint32_t* const head = qsets + (size_t)(e->qpar[split] & 1) * ENC_NQ * ENC_QSTRIDE;
+        uint32_t* const head_next = qsets + (size_t)((e->qpar[split] + 1) & 1) * ENC_NQ * ENC_QSTRIDE;
         const size_t nslots = e->sync_chunks;
         int32_t* const next_item = (int32_t*)e->next_item.p + next_item_used;
         next_item_used += (size_t)items + 16;
         EncodeArgs ea{(const ChunkDesc*)e->descs_enc.p, nchunks, plan.cp, (const uint8_t*)d_raw, (uint8_t*)e->scratch.p,
                       (StreamRec*)e->recs.p, lds_bytes, plan.total_blocks, split, dbg, head, plan.uniform_nblocks, whole_blocks,
                       nullptr, 0, nullptr,
-                      e->qbase[split], 0, fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
+                      head_next, 0, fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
                       sync + 16, sync + 16 + nslots, next_item, e->fold_gen};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ, zst = plan.cp.compcode == CODEC_ZSTD;
         void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : zst ? cimg_encode_streams_zstd : cimg_encode_streams;
@@ -695,8 +738,7 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             // waits for the small one
             if ((rc = e->hip(hipEventRecord(e->ev_side_done, e->s_side), "event record"))) return rc;
         }
-        // the queue deals out the items behind the first nwaves, and every wave pops exactly one past the end
-        e->qbase[split] += (uint32_t)(items - std::min(items, ea.nwaves)) + (uint32_t)ea.nwaves;
+        e->qpar[split] ^= 1;                          // the next launch of this kind pops the heads this one zeroes
     }
     if (side && (rc = e->hip(hipStreamWaitEvent(e->stream, e->ev_side_done, 0), "stream wait"))) return rc;
     if (leftovers) {
@@ -823,6 +865,15 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     EventPair ev{};
     const bool timed = e->timing;
     if (timed) { ev = e->get_events(); (void)hipEventRecord(ev.a, e->stream); e->timing = false; }   // lean + general = ONE timed decode
+    // The leftover blocks' launch may go to the side stream (below): it reads descs_dec and done[] like every decode launch, so it
+    // is ordered behind everything the main stream holds HERE -- uploads and memsets of this batch, producers of the chunks --
+    // and runs beside the lean launch that follows.  (Round 3 launched it unordered: a batch whose geometry differs from the one
+    // before could read the previous batch's descriptors.)
+    bool side_ordered = false;
+    if (lean && known_left && e->lean_last_skipped == 0 && !inputs_behind_stream && !e->no_side && !timed) {
+        if ((rc = e->side_follows_stream())) return rc;
+        side_ordered = true;
+    }
     if (lean) {
         // persistent waves, as many as are resident at once (registers: two per SIMD; LDS: 1280-byte granules per workgroup),
         // never more than there are blocks; wave w walks blocks w, w + G, ...
@@ -865,7 +916,11 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
         const bool beside = !inputs_behind_stream && !e->no_side && !timed;
         DecodeArgs dk = da;
         dk.blk_first = 0; dk.blk_step = 0;                  // workgroup k: the last block of chunk k (a chunk without a leftover block: done already)
-        if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
+        // (the side stream follows the main one up to the point right in front of the lean launch -- ev_side_pre, recorded there:
+        // this batch's descriptor upload and its `done` / stamp memsets lie before it, and so does whatever produced the chunks;
+        // what the side stream gains is running BESIDE the lean launch)
+        if (beside && !side_ordered) rc = e->side_follows_stream();              // (no lean launch in front after all: plain order)
+        if (!rc && !(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, dk, nchunks, 256, plan.lds_bytes, beside ? e->s_side : e->stream);
         if (!rc && beside) {
             if (!(rc = e->hip(hipEventRecord(e->ev_side_done, e->s_side), "event record")))

@@ -107,6 +107,7 @@ inline void fence_acquire() {}
 inline uint32_t atomic_add_agent(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t atomic_load_agent(const uint32_t* p) { return *p; }
 inline void atomic_store_agent(uint32_t* p, uint32_t v) { *p = v; }
+inline uint32_t atomic_exchange_agent(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = v; return o; }
 inline void wave_nap() {}
 inline void stores_performed() {}
 inline void atomic_count(uint32_t* p) { ++*p; }
@@ -247,6 +248,7 @@ CIMG_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"
 CIMG_DEV uint32_t atomic_add_agent(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CIMG_DEV uint32_t atomic_load_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CIMG_DEV void atomic_store_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+CIMG_DEV uint32_t atomic_exchange_agent(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every store this wave issued so far is acknowledged (write-through stores: at the memory side)
 CIMG_DEV void stores_performed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #ifndef CIMG_NAP_REPEAT

@@ -1,8 +1,8 @@
 // zstd_kernel.h -- blocks of zstd-coded chunks (blosc2 codec format 4), one wave per block.  The slow path of the decoder:
 // chunks the reference wrote with enums::codec::zstd (enums.h:18-24) stay readable.
 //
-// The engine launches this kernel only behind a batch in which cimg_decode_blocks reported ERR_CODEC_SUPPORT for some chunk
-// (engine.hip: decompress_finish clears STATUS_ZSTD_PENDING words only).  A block of any other chunk is left alone, whatever
+// The engine launches this kernel only behind a batch in which cimg_decode_blocks marked some chunk STATUS_ZSTD_PENDING (codec
+// format 4 in its header; engine.hip: decompress_finish clears exactly those words, launches, and reads the status again).  A block of any other chunk is left alone, whatever
 // its status says.  LDS: the block's streams decoded back to back (a frame's literals are regenerated inside its own output:
 // zstd_decode.h, zstd_block), 8 KiB through which the frame -- or, of a larger one, the section being decoded -- is read, the
 // entropy tables (ZstdWork): 52.5 KiB for 32 KiB blocks, three blocks per CU.  The decoder is issue bound (every lane executes

@@ -54,7 +54,14 @@ int  cimg_engine_synchronize(cimg_engine* e);
  * one -- _begin followed by _fetch below -- brackets them with these, on the same thread. */
 void cimg_engine_lock(cimg_engine* e);
 void cimg_engine_unlock(cimg_engine* e);
-void* cimg_engine_stream(cimg_engine* e);                     /* the hipStream_t every launch goes to */
+/* The hipStream_t the engine's work is ordered on.  A batch call behaves as if everything it does were enqueued there, in order:
+ * work the caller put on this stream before the call (a kernel producing the pixels, cimg_deinterleave_device) is seen by the
+ * batch, work put there after a _begin call follows the batch.  (Internally a batch may run one of its launches on a second
+ * stream beside the first -- the leftover blocks of chunks that are no multiple of the block size --; that stream is made to
+ * wait for everything this one holds when the batch is enqueued, and this one for it before the batch ends.)
+ * An encode launch is persistent: it is sized to fill the device, and it completes with any number of its workgroups resident
+ * (two engines, or two processes, sharing one card slow each other down; they do not wait for each other). */
+void* cimg_engine_stream(cimg_engine* e);
 
 /* ---- device-resident batches -----------------------------------------------------------------------
  * Chunk i's pixels live at d_raw + raw_off[i] (nbytes[i] bytes), its blosc2 chunk at
@@ -180,6 +187,13 @@ void cimg_engine_enable_timing(cimg_engine* e, int on);
 void cimg_engine_reset_timing(cimg_engine* e);
 /* total milliseconds and launch count of one kernel since the last reset (syncs the stream) */
 int  cimg_engine_kernel_time(cimg_engine* e, int kernel, double* total_ms, int64_t* launches);
+/* the duration of every timed launch since the last reset, in milliseconds, oldest first (for medians); returns how many were
+ * copied (at most max_samples), < 0 on error */
+int  cimg_engine_kernel_samples(cimg_engine* e, int kernel, float* ms, int max_samples);
+/* decode batches since the engine was created: how many went through the lean launch (cimg_decode_lean), how many blocks of
+ * those batches it left to cimg_decode_blocks (leftover blocks included), their block total, and how many batches needed
+ * cimg_decode_zstd.  Any pointer may be NULL. */
+void cimg_engine_decode_stats(cimg_engine* e, int64_t* lean_batches, int64_t* blocks_left_to_general, int64_t* blocks_total, int64_t* zstd_batches);
 const char* cimg_kernel_name(int kernel);
 
 /* ---- diagnostics: per-workgroup clock stamps of the most recent encode (0) / decode (1) launch ------

@@ -65,13 +65,13 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     int folded = 0;
     for (const ChunkDesc& d : plan.descs) { if (!d.assemble) leftovers = true; else folded++; }
     std::vector<uint32_t> chunk_count((size_t)nchunks, 0), ready((size_t)nchunks, 3);
-    const uint32_t gen = 5, qbase = 4294967000u;               // a queue head that counts on from earlier batches (and wraps in this one)
+    const uint32_t gen = 5;
     g_emu_folded = folded;
     for (int split = 1; split >= 0; split--) {
         const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;
         std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK);
-        uint32_t queue = qbase;
+        std::vector<uint32_t> queue((size_t)ENC_NQ * ENC_QSTRIDE, 0), queue_next((size_t)ENC_NQ * ENC_QSTRIDE, 77);
         bool block_items = split && g_emu_block_items;
         if (block_items)
             for (const ChunkDesc& d : plan.descs)
@@ -79,23 +79,25 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
         // 1: every block whole; 2: the first half whole, the rest plane by plane (the mixed queue of a small batch)
         const int whole_blocks = !block_items ? 0 : (g_emu_block_items == 2 ? plan.total_blocks / 2 : plan.total_blocks);
         const int zstride = 2 * (plan.cp.max_blocksize / 4 + 64);
-        std::vector<uint32_t> zseq((size_t)zstride * 4, 0xA5A5A5A5u);
+        std::vector<uint32_t> zseq((size_t)zstride * 80, 0xA5A5A5A5u);       // (a region per wave: up to 75 waves below)
         static ZstdEncTables ztabs;
         zstd_build_enc_tables(&ztabs);
-        // (the waves run one after the other here, so a wave that waits for a chunk another wave still has to finish would wait for
-        // ever: with in-launch assembly ONE wave does everything; three waves -- the static first items of waves 1 and 2 -- where the
-        // two assembly kernels run behind the launch)
-        const int emu_waves = folded ? 1 : 3;
+        // (the waves run one after the other here: the first drains every sub-queue -- its own, then the others as a thief --, the
+        // rest find them dry.  Every item is popped by a running wave, so a wave that waits for a chunk never waits for a wave
+        // that has not started.  The wave count rotates, so that different waves' "own" sub-queues come first.)
+        static int emu_wave_rot = 0;
+        const int emu_waves = 1 + (emu_wave_rot++ % 3) * 37;
         std::vector<int32_t> next_item((size_t)encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks) + 1, -7);
-        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, &queue, plan.uniform_nblocks, whole_blocks,
+        EncodeArgs ea{plan.descs.data(), nchunks, plan.cp, raw, scratch.data(), recs.data(), lds_bytes, plan.total_blocks, split, nullptr, queue.data(), plan.uniform_nblocks, whole_blocks,
                       zseq.data(), zstride, &ztabs,
-                      qbase, emu_waves, fold ? 1 : 0, comp, layout.data(), layout_host.data(), chunk_count.data(), ready.data(), next_item.data(), gen};
-        for (int w = 0; w < emu_waves; w++) {  // persistent waves: each takes item w first, the first one then drains the queue
+                      queue_next.data(), emu_waves, fold ? 1 : 0, comp, layout.data(), layout_host.data(), chunk_count.data(), ready.data(), next_item.data(), gen};
+        for (int w = emu_waves - 1; w >= 0; w--) {  // persistent waves, the highest-numbered first (so that wave 0, which zeroes the next launch's heads, is not the one that encodes)
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
             else if (plan.cp.compcode == CODEC_ZSTD) { EncodeStream<CODEC_ZSTD> es(&ea, lds.data(), w); es.run(); }
             else { EncodeStream<CODEC_LZ4> es(&ea, lds.data(), w); es.run(); }
         }
+        for (int q = 0; q < ENC_NQ; q++) if (queue_next[(size_t)q * ENC_QSTRIDE] != 0) return -1;   // the next launch's heads were zeroed
     }
     if (layout_host[(size_t)nchunks].cbytes < 0) return -1;                      // a wave waited in vain
     for (int c = 0; c < nchunks; c++) if (chunk_count[(size_t)c] != 0) return -1;   // every closer puts its count back to zero

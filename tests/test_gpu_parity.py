@@ -1072,3 +1072,113 @@ def test_every_combination_of_plane_kinds_decodes_on_the_gpu(eng, compcode):
             for o in outs:
                 bad = np.nonzero(o != raw)[0]
                 assert bad.size == 0, (ts, compcode, "first wrong byte %d = block %d" % (bad[0], bad[0] // 32768))
+
+
+def test_two_engines_encode_concurrently_with_partly_resident_launches(eng):
+    """Two engines, two threads, sixty configs[1] compress batches each, at the same time (encode_kernel.h:
+    EncodeArgs::claim, EncodeStream::run).  Each encode launch is sized to fill the device, so the workgroups of one are partly
+    NOT resident while the other runs -- and a wave that is out of queue work waits, inside the launch, for its chunks to close.
+    First items are claimed, and waiting waves take over the unclaimed ones, so every launch completes with whatever is resident:
+    no batch may fail (cbytes -1 = "a chunk was never published"), and every batch's bytes are the oracle's."""
+    import threading
+    chans = [synth.tiled_channel(np.float16, 4096, 4096, c=c) for c in range(4)]
+    host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    n, chunk = host.size, 4 * 1024 * 1024
+    nchunks, stride = n // chunk, chunk + 64
+    raw_off = np.arange(nchunks, dtype=np.int64) * chunk
+    comp_off = np.arange(nchunks, dtype=np.int64) * stride
+    cb_want, chunk_want = _oracle_all_chunks(O.cparams(2), host, chunk)
+    want = np.zeros(nchunks * stride, np.uint8)
+    for i in range(nchunks):
+        want[i * stride:i * stride + cb_want[i]] = chunk_want(i)
+    engines = [eng, hip.Engine(0)]
+    bufs = []
+    for e in engines:
+        d_raw, d_comp = e.alloc(n), e.alloc(nchunks * stride)
+        d_raw.upload(host)
+        bufs.append((d_raw, d_comp))
+    errors = []
+    start = threading.Barrier(2)
+
+    def worker(k):
+        e, (d_raw, d_comp) = engines[k], bufs[k]
+        try:
+            start.wait()
+            for rep in range(60):
+                cb = e.compress_device(hip.cparams(2), d_raw.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+                assert (np.asarray(cb) == cb_want).all(), (k, rep, "sizes")
+                if rep % 10 == 9 or rep == 0:
+                    blob = d_comp.download()
+                    for i in range(nchunks):
+                        assert blob[i * stride:i * stride + cb[i]].tobytes() == want[i * stride:i * stride + cb[i]].tobytes(), (k, rep, i)
+        except BaseException as ex:                        # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    alive = [t.is_alive() for t in threads]
+    for (d_raw, d_comp) in bufs:
+        d_raw.free(); d_comp.free()
+    engines[1].close()
+    assert not any(alive), "an encode batch did not come back"
+    assert not errors, errors
+
+
+def test_decode_batches_of_alternating_geometry_with_leftover_blocks(eng):
+    """the leftover blocks' decode launch runs on the side stream; it reads the batch's descriptors, so it must
+    be ordered behind their upload.  Two geometries (chunk counts, chunk sizes, offsets) ALTERNATE through the device-resident
+    call -- every batch uploads new descriptors -- and every batch's pixels are compared."""
+    geos = []
+    for chunk, nchunks, fam in ((31 * 32768 + 31744, 12, synth.tiled_channel), (17 * 32768 + 2048, 7, synth.tiled_channel), (9 * 32768 + 30000, 20, synth.natural_channel)):
+        raw = np.ascontiguousarray(fam(np.float16, 1024, chunk * nchunks // 2048 + 1)).view(np.uint8).ravel()[:chunk * nchunks]
+        stride = (chunk + 32 + 63) // 64 * 64
+        chunks = [O.compress(O.cparams(2), raw[i * chunk:(i + 1) * chunk], destsize=chunk + 32)[1] for i in range(nchunks)]
+        blob = np.zeros(stride * nchunks, np.uint8)
+        for i, c in enumerate(chunks):
+            blob[i * stride:i * stride + len(c)] = np.frombuffer(c, np.uint8)
+        d_comp, d_out = eng.alloc(blob.size), eng.alloc(raw.size)
+        d_comp.upload(blob)
+        geos.append((chunk, nchunks, raw, stride, d_comp, d_out))
+    for rep in range(12):
+        chunk, nchunks, raw, stride, d_comp, d_out = geos[rep % len(geos)]
+        d_out.upload(np.zeros(raw.size, np.uint8))
+        eng.decompress_device(d_comp.ptr, np.arange(nchunks, dtype=np.int64) * stride, [chunk] * nchunks, [32768] * nchunks, d_out.ptr,
+                              np.arange(nchunks, dtype=np.int64) * chunk)
+        assert d_out.download(raw.size).tobytes() == raw.tobytes(), rep
+    for g in geos:
+        g[4].free(); g[5].free()
+
+
+def test_deinterleave_on_the_device_then_compress_with_leftover_blocks(eng):
+    """cimg_deinterleave_device returns with its kernel enqueued on the engine's stream; a compress batch right
+    behind it whose chunks have leftover blocks (their launch runs on the side stream) must still see the planes the kernel
+    writes.  Alternating pictures, so that stale planes would show: chunks against the oracle's for the planar pixels."""
+    nch, width, rows = 3, 1920, 24                                         # float16 rows of 3840 bytes: chunks with a leftover block
+    npix = width * rows
+    plane_bytes = npix * 2
+    plane_stride = (plane_bytes + 15) & ~15
+    chunk = plane_bytes // 2                                              # two chunks per plane: 46080 bytes = 1 block + 13312
+    assert chunk % 32768 != 0 and plane_bytes % chunk == 0
+    nchunks = nch * 2
+    raw_off = np.array([c * plane_stride + k * chunk for c in range(nch) for k in range(2)], dtype=np.int64)
+    stride = (chunk + 32 + 63) // 64 * 64
+    comp_off = np.arange(nchunks, dtype=np.int64) * stride
+    d_il, d_planar, d_comp = eng.alloc(npix * nch * 2), eng.alloc(plane_stride * nch), eng.alloc(stride * nchunks)
+    for rep in range(6):
+        planes = [np.ascontiguousarray(synth.tiled_channel(np.float16, width, rows, c=c, seed=100 + rep)).ravel() for c in range(nch)]
+        il = np.stack(planes, axis=1).ravel()                             # R G B R G B ...
+        d_il.upload(il.view(np.uint8))
+        eng.deinterleave_device(d_il.ptr, nch, 2, npix, d_planar.ptr, plane_stride)
+        cb = eng.compress_device(hip.cparams(2), d_planar.ptr, raw_off, [chunk] * nchunks, d_comp.ptr, comp_off, [chunk + 32] * nchunks)
+        blob = d_comp.download(stride * nchunks)
+        for c in range(nch):
+            pb = planes[c].view(np.uint8)
+            for k in range(2):
+                i = 2 * c + k
+                r, want = O.compress(O.cparams(2), pb[k * chunk:(k + 1) * chunk], destsize=chunk + 32)
+                assert cb[i] == r and blob[i * stride:i * stride + r].tobytes() == want, (rep, c, k)
+    for b in (d_il, d_planar, d_comp):
+        b.free()

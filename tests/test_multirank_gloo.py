@@ -70,6 +70,21 @@ def _worker(rank, world, port, out):
                 assert O.decompress(got[i])[1].tobytes() == raw[i * chunk:(i + 1) * chunk].tobytes()
         else:
             assert got is None
+        # ---- the decode mirror: rank 0 holds the whole image's chunks (just gathered), every owner gets ITS chunks back, exact sizes,
+        # and decodes them; the sizes table travels first (a reader of a stored image knows it on one rank only)
+        sizes_b = shard.broadcast_sizes(dist, full if rank == 0 else None, n, src=0)
+        assert sizes_b.tolist() == list(full)
+        if rank == 0:
+            whole, offs, _ = packed
+            mine_buf, mine_off, mine_idx = shard.scatter_chunks(dist, world, rank, whole, offs, sizes_b, n, src=0, items_per_group=4)
+        else:
+            mine_buf, mine_off, mine_idx = shard.scatter_chunks(dist, world, rank, None, None, sizes_b, n, src=0, items_per_group=4)
+        assert mine_idx.tolist() == mine.tolist()
+        assert mine_buf.numel() == int(sizes_b[mine].sum())                 # nothing padded
+        for k, g in enumerate(mine_idx):
+            c = mine_buf[int(mine_off[k]):int(mine_off[k]) + int(sizes_b[g])].numpy()
+            assert c.tobytes() == blobs[k].tobytes()                         # the chunk this rank compressed came back byte for byte
+            assert O.decompress(c)[1].tobytes() == raw[g * chunk:(g + 1) * chunk].tobytes()
         out.put((rank, mine.tolist(), full.tolist(), t, digest))
     finally:
         dist.destroy_process_group()
