@@ -55,7 +55,7 @@ def visible_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
-def cpu_baseline(host, budget_s=10.0, policy="share", typesize=2, compcode=None, chunk=None, threads=None):
+def cpu_baseline(host, budget_s=10.0, policy="share", typesize=2, compcode=None, chunk=None, threads=None, filt=None, destsize=None):
     """The oracle (C, -O3, OpenMP inside the library: no Python in the timed region) over the same chunks.
 
     policy "share":     an OpenMP loop over chunks on THIS GPU's share of the host cores (16 of an 8-GPU host's 128 cores / 256
@@ -78,11 +78,19 @@ def cpu_baseline(host, budget_s=10.0, policy="share", typesize=2, compcode=None,
         cores = threads or avail
         teams = min(cores, nchunks)
         enc = dec = (teams, max(1, cores // teams))
+    elif policy == "one":
+        cores = 1
+        enc = dec = (1, 1)
+    elif policy == "blocks16":                                # one chunk at a time, this GPU's share of the host over its blocks
+        cores = min(avail, 16)
+        enc, dec = (1, cores), (1, cores)
     else:
         cores = max(1, avail // 2)
         enc, dec = (1, cores), (1, 1)
-    p = O.cparams(typesize, clevel=9, blocksize=BLOCK, compcode=O.LZ4 if compcode is None else compcode)
-    stride = chunk + 64
+    p = O.cparams(typesize, clevel=9, blocksize=BLOCK, compcode=O.LZ4 if compcode is None else compcode,
+                  **({} if filt is None else {"filters": (0, 0, 0, 0, 0, filt)}))
+    destsize = destsize or chunk + 32
+    stride = max(chunk, destsize) + 64
     comp = np.zeros(nchunks * stride, np.uint8)
     out = np.zeros(host.size, np.uint8)
     cb = np.zeros(nchunks, np.int32)
@@ -90,7 +98,7 @@ def cpu_baseline(host, budget_s=10.0, policy="share", typesize=2, compcode=None,
 
     def one_pass():
         t0 = time.perf_counter()
-        r = L.orc_bench_compress(C.byref(p), vp(host), nchunks, chunk, vp(comp), stride, chunk + 32, vp(cb), enc[0], enc[1])
+        r = L.orc_bench_compress(C.byref(p), vp(host), nchunks, chunk, vp(comp), stride, destsize, vp(cb), enc[0], enc[1])
         t1 = time.perf_counter()
         d = L.orc_bench_decompress(vp(comp), nchunks, stride, vp(cb), vp(out), chunk, dec[0], dec[1])
         t2 = time.perf_counter()
@@ -109,7 +117,7 @@ def cpu_baseline(host, budget_s=10.0, policy="share", typesize=2, compcode=None,
     return {"value": round(reps * 2 * n / (te + td) / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
             "compress_GBps": round(reps * n / te / 1e9, 3), "decompress_GBps": round(reps * n / td / 1e9, 3),
             "policy": policy,
-            "sample": f"oracle (oracle/ CPU restatement at -O3, not c-blosc2): the same {nchunks} chunks x {chunk >> 20} MiB, {reps} passes in "
+            "sample": f"oracle (oracle/ CPU restatement at -O3, not c-blosc2): the same {nchunks} chunk(s) x {chunk >> 20} MiB, {reps} passes in "
                       f"{te + td:.1f} s; compress: {enc[0]} thread(s) over chunks x {enc[1]} over blocks, decompress: "
                       f"{dec[0]} x {dec[1]} ({avail} hardware threads visible)"}
 
@@ -165,7 +173,7 @@ TIMING_PERIOD = 4
 FILTER_TEXT = {"shuffle": "byte shuffle", "bitshuffle": "bitshuffle (one unsplit stream per block)", "none": "no filter"}
 FETCH_FACTOR = 2.0
 # the decode entry of the engine timers covers two launches (lean kernel + general kernel behind it)
-PMC_KERNELS = {"cimg_decode_blocks": ("cimg_decode_lean", "cimg_decode_blocks")}
+PMC_KERNELS = {"cimg_decode_blocks": ("cimg_decode_lean", "cimg_decode_blocks")}     # (keyed by the engine's timing ids' names, cimg/hip.py KERNELS)
 
 
 def kernel_source_hash():
@@ -180,7 +188,7 @@ def kernel_source_hash():
 
 
 def pmc_traffic(kernel, explicit=None):
-    path = explicit or os.path.join(ROOT, "profiles", "r03", "pmc_per_launch.json")
+    path = explicit or next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_per_launch.json") for r in ("r04", "r03")) if os.path.exists(q)), "")
     if not os.path.exists(path):
         return None, None
     try:
@@ -199,6 +207,278 @@ def pmc_traffic(kernel, explicit=None):
     except (OSError, ValueError):
         pass
     return None, None
+
+
+def measure_copy_peak(nbytes=256 << 20, reps=12):
+    """The HBM rate a plain device-to-device copy reaches on THIS card, in this process (fractions are
+    quoted against the 8 TB/s specification AND against a measured copy peak): torch's vectorised copy kernel over buffers far
+    larger than the caches, HIP events on torch's stream.  bytes moved = read + written."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda").fill_(7)
+    b = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        gbps = 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        best = gbps if best is None or gbps > best else best
+    del a, b
+    return round(best, 1)
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return 0.5 * (xs[(len(xs) - 1) // 2] + xs[len(xs) // 2]) if xs else 0.0
+
+
+def run_config1(args, rank, world, local_rank, dist, red_dev):
+    """BASELINE configs[0]: ONE 1024 x 1024 uint8 channel, blosclz + byte shuffle, default chunk size -- the reference's own
+    CPU-runnable plumbing case (test/src/test_channel.cpp:74-87 shape).  The default chunk size is 4 MiB, so the channel is ONE chunk
+    of 1 MiB (32 blocks): a step = compress it + decompress it, device-resident, through the single-chunk form of the batched calls
+    (what one blosc2_compress_ctx / blosc2_decompress_ctx of the reference becomes).  32 blocks cannot fill 256 CUs: this line is
+    the latency floor of the path, not a throughput claim."""
+    import _oracle as O
+    from cimg import hip, synth
+    W = H = 1024
+    codec = args.codec or "blosclz"
+    gen = getattr(synth, args.family + "_channel")
+    chan = gen(np.uint8, W, H) if args.family == "zero" else gen(np.uint8, W, H, c=rank)
+    host = chan.view(np.uint8).ravel()
+    N = host.size
+    d_raw = torch.from_numpy(host).cuda()
+    d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    d_comp = torch.zeros(CHUNK + 64, dtype=torch.uint8, device="cuda")
+    eng = hip.Engine(local_rank)
+    filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[args.filter or "shuffle"]
+    compcode = hip.BLOSCLZ if codec == "blosclz" else hip.LZ4
+    p = hip.cparams(1, clevel=9, blocksize=BLOCK, compcode=compcode, filters=(0, 0, 0, 0, 0, filt))
+    step = eng.roundtrip_calls(p, d_raw.data_ptr(), [0], [N], d_comp.data_ptr(), [0], [CHUNK + 32], [BLOCK], d_out.data_ptr())
+    cb = step().copy()
+    if not torch.equal(d_out, d_raw):
+        print("bench.py --config 1: decompressed pixels differ from the input", file=sys.stderr)
+        sys.exit(3)
+    po = O.cparams(1, clevel=9, blocksize=BLOCK, compcode=O.BLOSCLZ if codec == "blosclz" else O.LZ4, filters=(0, 0, 0, 0, 0, filt))
+    r, want = O.compress(po, host, destsize=CHUNK + 32)
+    same_bytes = int(cb[0]) == r and d_comp[:r].cpu().numpy().tobytes() == want
+    for _ in range(args.warmup):
+        step()
+    eng.enable_timing(1)
+    eng.reset_timing()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    per_step = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if k == args.steps - 1:
+            d_out.zero_()                                       # the last step's pixels are checked: they must be written by it
+            torch.cuda.synchronize()
+        ts = time.perf_counter()
+        step()
+        per_step.append(time.perf_counter() - ts)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not torch.equal(d_out, d_raw):
+        print("bench.py --config 1: pixels differ after the timed region", file=sys.stderr)
+        sys.exit(3)
+    enc = eng.kernel_samples(hip.K_ENCODE) * 1e3
+    dec = eng.kernel_samples(hip.K_DECODE) * 1e3
+    eng.enable_timing(False)
+    Cb = int(cb[0])
+    if rank == 0:
+        e_us, d_us = _median(enc.tolist()), _median(dec.tolist())
+        out = {"metric": "compress+decompress GB/s (uncompressed side)", "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3), "unit": "GB/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "ms_per_step_median": round(_median(per_step) * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[0]: 1x{W}x{H} uint8, {codec} clevel 9 + {FILTER_TEXT[args.filter or 'shuffle']}, one chunk of 1 MiB in a "
+                                      f"4 MiB + 32 buffer (32 blocks of 32 KiB), device-resident, family={args.family}; single-chunk calls",
+                          "element_dtype": "uint8", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": Cb,
+                          "compression_ratio": round(N / Cb, 4) if Cb else None, "bytes_equal_oracle": bool(same_bytes),
+                          "us_per_chunk_roundtrip": round(elapsed / args.steps * 1e6, 1)},
+               "roofline": {"kernel": "cimg_encode_streams_blosclz" if codec == "blosclz" else "cimg_encode_streams", "bound": "hbm",
+                            "achieved": round((N + Cb) / (e_us * 1e-6) / 1e9, 1) if e_us else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round((N + Cb) / (e_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if e_us else None, "traffic": None,
+                            "algorithmic_bytes_per_launch": N + Cb, "median_launch_us": round(e_us, 2),
+                            "note": "32 work items on a device that holds 1280 chains: the launch is one chain's latency"},
+               "roofline_decode": {"kernel": "cimg_decode_lean + cimg_decode_blocks", "bound": "hbm", "median_launch_us": round(d_us, 2),
+                                   "achieved": round((N + Cb) / (d_us * 1e-6) / 1e9, 1) if d_us else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": round((N + Cb) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if d_us else None}}
+        if not args.no_cpu_baseline and world == 1:
+            # the reference's own call: one thread team over the blocks of the one chunk (channel.h:127: hw / 2 threads) for compression,
+            # ONE thread for decompression (wrapper.h:406)
+            # (this GPU's share of the host -- 16 threads over the blocks of the one chunk --, then the reference's hw / 2 threads, which
+            # on a box that shows 256 hardware threads to a container scheduled on 16 cores mostly thrash, then one thread)
+            out["cpu_baseline"] = cpu_baseline(host, budget_s=4.0, policy="blocks16", typesize=1, compcode=po.compcode, chunk=N, filt=filt, destsize=CHUNK + 32)
+            out["cpu_baseline_reference_policy"] = cpu_baseline(host, budget_s=3.0, policy="reference", typesize=1, compcode=po.compcode, chunk=N, filt=filt, destsize=CHUNK + 32)
+            out["cpu_baseline_one_thread"] = cpu_baseline(host, budget_s=3.0, policy="one", typesize=1, compcode=po.compcode, chunk=N, filt=filt, destsize=CHUNK + 32)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_config3(args, rank, world, local_rank, dist, red_dev):
+    """BASELINE configs[2]: 8192 x 8192 uint16, 3 channels, blosclz + bitshuffle, the random-access loop of the reference's
+    examples/lazy_channels/main.cpp:35-52 (channel.h:502-538): visit the chunks in a seeded random permutation (rng 99, SURVEY.md
+    section 8d), get_chunk -> every pixel + 1 -> set_chunk.  Device-resident SINGLE-CHUNK calls: one cimg_decompress_batch_device of
+    one chunk into a work buffer, the + 1 on the device (on the engine's stream), one cimg_compress_batch_device of one chunk back
+    into its slot.  A step = one pass over the permutation of all 96 chunks (4 MiB each); GB/s counts the uncompressed bytes decoded
+    + encoded.  128 blocks per call on a 256-CU device: this is the latency-bound face of the path, reported as such."""
+    import _oracle as O
+    from cimg import hip, synth
+    W = H = 8192
+    NCH = 3
+    codec = args.codec or "blosclz"
+    filt_name = args.filter or "bitshuffle"
+    gen = getattr(synth, args.family + "_channel")
+    chans = [gen(np.uint16, W, H) if args.family == "zero" else gen(np.uint16, W, H, c=NCH * rank + c) for c in range(NCH)]
+    host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    N = host.size
+    nchunks = N // CHUNK
+    stride = CHUNK + 64
+    d_raw = torch.from_numpy(host).cuda()
+    d_comp = torch.zeros(nchunks * stride, dtype=torch.uint8, device="cuda")
+    d_work = torch.zeros(CHUNK, dtype=torch.uint8, device="cuda")
+    raw_off = np.arange(nchunks, dtype=np.int64) * CHUNK
+    comp_off = np.arange(nchunks, dtype=np.int64) * stride
+    eng = hip.Engine(local_rank)
+    filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[filt_name]
+    compcode = hip.BLOSCLZ if codec == "blosclz" else hip.LZ4
+    p = hip.cparams(2, clevel=9, blocksize=BLOCK, compcode=compcode, filters=(0, 0, 0, 0, 0, filt))
+    cb0 = eng.compress_device(p, d_raw.data_ptr(), raw_off, [CHUNK] * nchunks, d_comp.data_ptr(), comp_off, [CHUNK + 32] * nchunks)   # the channels as the constructor leaves them
+    perm = np.random.default_rng(99).permutation(nchunks)
+    get_chunk, set_chunk = eng.single_chunk_calls(p, d_work.data_ptr(), d_comp.data_ptr(), comp_off, CHUNK, CHUNK + 32, BLOCK)
+    work16 = d_work.view(torch.int16)                               # (+ 1 wraps the same way for int16 and uint16 bit patterns)
+    ext = torch.cuda.ExternalStream(eng.stream_handle(), device=torch.device("cuda", local_rank))
+    sizes = np.asarray(cb0, np.int64).copy()
+
+    def one_pass():
+        with torch.cuda.stream(ext):
+            for i in perm:
+                get_chunk(int(i))
+                work16.add_(1)                                      # on the engine's stream: the compress batch behind it sees the result
+                sizes[i] = set_chunk(int(i))
+
+    passes_done = 0
+    for _ in range(max(args.warmup, 1)):
+        one_pass(); passes_done += 1
+    eng.enable_timing(1)
+    eng.reset_timing()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    per_step = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        one_pass(); passes_done += 1
+        per_step.append(time.perf_counter() - ts)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    enc = eng.kernel_samples(hip.K_ENCODE) * 1e3
+    dec = eng.kernel_samples(hip.K_DECODE) * 1e3
+    eng.enable_timing(False)
+    # every pixel went up by one per pass: decode everything in one batch and compare
+    d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    eng.decompress_device(d_comp.data_ptr(), comp_off, [CHUNK] * nchunks, [BLOCK] * nchunks, d_out.data_ptr(), raw_off)
+    want = (host.view(np.uint16) + np.uint16(passes_done)).view(np.uint8)
+    if d_out.cpu().numpy().tobytes() != want.tobytes():
+        print("bench.py --config 3: the channels do not hold pixels + passes after the loop", file=sys.stderr)
+        sys.exit(3)
+    visits = args.steps * nchunks
+    Cb = float(sizes.sum())
+    if rank == 0:
+        e_us, d_us = _median(enc.tolist()), _median(dec.tolist())
+        cmean = Cb / nchunks
+        out = {"metric": "compress+decompress GB/s (uncompressed side), random-access get_chunk -> +1 -> set_chunk loop",
+               "value": round(world * visits * 2 * CHUNK / elapsed / 1e9, 3), "unit": "GB/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "ms_per_step_median": round(_median(per_step) * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[2]: {NCH}x{W}x{H} uint16 per GPU, {codec} clevel 9 + {FILTER_TEXT[filt_name]}, 32 KiB blocks, 4 MiB chunks "
+                                      f"({nchunks} chunks), seeded random permutation (rng 99), get_chunk -> +1 -> set_chunk per chunk, "
+                                      f"single-chunk device-resident calls, family={args.family}; a step = one pass over all {nchunks} chunks",
+                          "element_dtype": "uint16", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(Cb),
+                          "compression_ratio": round(N / Cb, 4) if Cb else None,
+                          "us_per_chunk_visit": round(elapsed / visits * 1e6, 1), "chunk_visits": visits},
+               "roofline": {"kernel": "cimg_encode_streams_blosclz" if codec == "blosclz" else "cimg_encode_streams", "bound": "hbm",
+                            "achieved": round((CHUNK + cmean) / (e_us * 1e-6) / 1e9, 1) if e_us else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round((CHUNK + cmean) / (e_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if e_us else None, "traffic": None,
+                            "algorithmic_bytes_per_launch": int(CHUNK + cmean), "median_launch_us": round(e_us, 2),
+                            "note": "one chunk = 128 blocks per launch on a device that holds 1280 encode chains / 2048 decode waves: the launch is "
+                                    "a single chain's latency (kernels incl. leftover-free assembly; medians of every launch in the timed region)"},
+               "roofline_decode": {"kernel": "cimg_decode_lean + cimg_decode_blocks", "bound": "hbm", "median_launch_us": round(d_us, 2),
+                                   "achieved": round((CHUNK + cmean) / (d_us * 1e-6) / 1e9, 1) if d_us else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": round((CHUNK + cmean) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if d_us else None}}
+        if not args.no_cpu_baseline and world == 1:
+            # the same loop on the host: the reference's call structure (one chunk at a time; compression with hw / 2 threads over the
+            # chunk's blocks, channel.h:127; decompression on one thread, wrapper.h:406; the + 1 in numpy) on a bounded sample of chunks
+            cc = O.BLOSCLZ if codec == "blosclz" else O.LZ4
+            out["cpu_baseline"] = cpu_random_access(host, perm, compcode=cc, filt=filt, budget_s=8.0, cthreads=min(visible_cores(), 16), dthreads=min(visible_cores(), 16))
+            out["cpu_baseline_reference_policy"] = cpu_random_access(host, perm, compcode=cc, filt=filt, budget_s=6.0, cthreads=max(1, visible_cores() // 2), dthreads=1)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_random_access(host, perm, compcode, filt, budget_s=12.0, cthreads=16, dthreads=16):
+    """configs[2]'s loop on the host cores through the oracle (kind "port"): per visited chunk one decompress, + 1, one compress, each
+    with its threads over the blocks of the ONE chunk (the reference's call structure: hw / 2 threads for compression, channel.h:127,
+    ONE for decompression, wrapper.h:406; or this GPU's 16-thread share of the host for both).  Bounded: as many chunks of the
+    permutation as fit the budget."""
+    L, O = _oracle_batch_lib()
+    avail = visible_cores()
+    p = O.cparams(2, clevel=9, blocksize=BLOCK, compcode=compcode, filters=(0, 0, 0, 0, 0, filt))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    comp = np.zeros(CHUNK + 64, np.uint8)
+    cb = np.zeros(1, np.int32)
+    work = np.zeros(CHUNK, np.uint8)
+    tdec = tadd = tenc = 0.0
+    visited = 0
+    t_start = time.perf_counter()
+    for i in perm:
+        src = host[int(i) * CHUNK:(int(i) + 1) * CHUNK]
+        r = L.orc_bench_compress(C.byref(p), vp(src), 1, CHUNK, vp(comp), CHUNK + 64, CHUNK + 32, vp(cb), 1, cthreads)     # (the chunk as it sits in the channel: not timed)
+        assert r > 0
+        t0 = time.perf_counter()
+        d = L.orc_bench_decompress(vp(comp), 1, CHUNK + 64, vp(cb), vp(work), CHUNK, 1, dthreads)
+        t1 = time.perf_counter()
+        w16 = work.view(np.uint16); w16 += np.uint16(1)
+        t2 = time.perf_counter()
+        r = L.orc_bench_compress(C.byref(p), vp(work), 1, CHUNK, vp(comp), CHUNK + 64, CHUNK + 32, vp(cb), 1, cthreads)
+        t3 = time.perf_counter()
+        assert d == CHUNK and r > 0
+        tdec += t1 - t0; tadd += t2 - t1; tenc += t3 - t2; visited += 1
+        if time.perf_counter() - t_start > budget_s:
+            break
+    total = tdec + tadd + tenc
+    return {"value": round(visited * 2 * CHUNK / total / 1e9, 3), "unit": "GB/s", "cores": cthreads, "kind": "port",
+            "us_per_chunk_visit": round(total / visited * 1e6, 1), "decompress_us": round(tdec / visited * 1e6, 1), "plus_one_us": round(tadd / visited * 1e6, 1),
+            "compress_us": round(tenc / visited * 1e6, 1),
+            "sample": f"oracle (CPU restatement, not c-blosc2): {visited} chunks of the same permutation, per chunk decompress on {dthreads} thread(s), "
+                      f"+ 1 in numpy, compress on {cthreads} threads over the chunk's blocks; {avail} hardware threads visible"}
 
 
 def run_config5(args, rank, world, local_rank, dist, red_dev):
@@ -367,15 +647,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--family", default="tiled", choices=["tiled", "natural", "random", "zero"])
     ap.add_argument("--zstd-clevel", type=int, default=9, help="--config 5: blosc2 clevel the chunks are made with (9 = the reference's default = zstd level 22)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
-                    help="BASELINE.json configuration, counted from 1: 2 = configs[1], 4 x 4096^2 float16 per rank (the headline); "
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configuration, counted from 1: 1 = configs[0], one 1024^2 uint8 channel, blosclz + shuffle (one 1 MiB chunk: "
+                         "the latency floor); 2 = configs[1], 4 x 4096^2 float16 per rank (the headline); "
+                         "3 = configs[2], 3 x 8192^2 uint16 blosclz + bitshuffle, the seeded random-access get_chunk -> +1 -> set_chunk loop "
+                         "(single-chunk calls; a step = one pass over the 96 chunks); "
                          "4 = configs[3], 64 such images over 8 GPUs = 8 images per rank, with the gather of the finished chunks to rank 0; "
                          "5 = configs[4], 16384^2 float32 zstd: one channel per rank, decode of libzstd-made chunks + compression ratio")
-    ap.add_argument("--codec", default="lz4", choices=["lz4", "blosclz"], help="not part of the headline (BASELINE configs[1] is lz4)")
+    ap.add_argument("--codec", default=None, choices=["lz4", "blosclz"], help="default: what the configuration names (lz4 for 2 / 4, blosclz for 1 / 3)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--config 2 with N > 1: weak = every rank owns its own 4 channels (per-GPU work fixed); strong = the ONE image's 32 chunks are "
+                         "split over the ranks as cimg/shard.py partition(32, world, rank, 8) does (total work fixed: 4 chunks per GPU at 8)")
     ap.add_argument("--pmc-json", default=None, help="per-launch PMC averages to take roofline.traffic from (profiles/tools/collect.sh)")
-    ap.add_argument("--filter", default="shuffle", choices=["shuffle", "bitshuffle", "none"],
-                    help="not part of the headline: the reference only uses byte shuffle")
+    ap.add_argument("--filter", default=None, choices=["shuffle", "bitshuffle", "none"],
+                    help="default: what the configuration names (byte shuffle; bitshuffle for 3)")
     args = ap.parse_args()
+    if args.config in (1, 3) and args.steps == 50 and "--steps" not in sys.argv:
+        args.steps = 200 if args.config == 1 else 5            # (a step of configs[0] is one 1 MiB chunk, of configs[2] a pass over 96 chunks)
+    if args.config in (1, 3) and "--warmup" not in sys.argv:
+        args.warmup = 20 if args.config == 1 else 1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -406,6 +696,12 @@ def main():
 
     if args.config == 5:
         return run_config5(args, rank, world, local_rank, dist, red_dev)
+    if args.config == 1:
+        return run_config1(args, rank, world, local_rank, dist, red_dev)
+    if args.config == 3:
+        return run_config3(args, rank, world, local_rank, dist, red_dev)
+    args.codec = args.codec or "lz4"
+    args.filter = args.filter or "shuffle"
 
     from cimg import hip, synth
 
@@ -422,6 +718,20 @@ def main():
             else:
                 chans.append(gen(DTYPE, WIDTH, HEIGHT, c=CHANNELS * rank + c))
     host = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    strong = args.scaling == "strong" and args.config == 2
+    if args.scaling == "strong" and not strong:
+        print("bench.py: --scaling strong is defined for --config 2 (one image's 32 chunks over the ranks)", file=sys.stderr)
+        sys.exit(2)
+    N_image = host.size
+    if strong:
+        # ONE image for the whole job (rank 0's channels, the N = 1 workload): SURVEY.md section 8e -- channels round-robin while there
+        # are at least as many as ranks, chunk-granular below that (8 GPUs: chunks r, r + 8, r + 16, r + 24)
+        from cimg import shard
+        chans = [gen(DTYPE, WIDTH, HEIGHT) if args.family == "zero" else gen(DTYPE, WIDTH, HEIGHT, c=c) for c in range(CHANNELS)]
+        whole = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+        mine_chunks = shard.partition(whole.size // CHUNK, world, rank, items_per_group=whole.size // CHUNK // CHANNELS)
+        host = np.concatenate([whole[int(g) * CHUNK:(int(g) + 1) * CHUNK] for g in mine_chunks]) if len(mine_chunks) else np.zeros(0, np.uint8)
+        N_image = whole.size
     N = host.size
     nchunks = N // CHUNK
     stride = CHUNK + 64
@@ -481,9 +791,17 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    per_step = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if k == args.steps - 1:
+            # the LAST step's pixels are the ones compared below: d_out is cleared in front of it (inside the timed region: 25 us of
+            # memset once), so a decode that wrote nothing could not pass on the pixels an earlier step left there
+            d_out.zero_()
+            torch.cuda.synchronize()
+        ts = time.perf_counter()
         step()
+        per_step.append(time.perf_counter() - ts)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -500,7 +818,18 @@ def main():
         total_c = float(cbytes.sum())
 
     ktimes = [eng.kernel_time(k) for k in range(4)]
+    ksamples = [eng.kernel_samples(k) for k in range(4)]
+    dstats = eng.decode_stats()
     eng.enable_timing(False)
+    # per-rank kernel time (strong scaling shows the latency floor: a rank with 4 chunks still pays a whole chain round per launch)
+    per_rank_us = None
+    mine_us = [float(np.median(ksamples[hip.K_ENCODE])) * 1e3 if len(ksamples[hip.K_ENCODE]) else 0.0,
+               float(np.median(ksamples[hip.K_DECODE])) * 1e3 if len(ksamples[hip.K_DECODE]) else 0.0]
+    if dist is not None:
+        tk = torch.zeros(world, 2, dtype=torch.float64, device=red_dev)
+        tk[rank, 0], tk[rank, 1] = mine_us[0], mine_us[1]
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+        per_rank_us = [[round(float(tk[r, 0]), 2), round(float(tk[r, 1]), 2)] for r in range(world)]
 
     # ---- the exchange step of SURVEY.md section 8e (N > 1): every rank's finished chunks travel to rank 0, packed,
     # point to point with exact sizes (cimg/shard.py: gather_chunks; "nccl" = RCCL send/recv over xGMI).  Timed on its own,
@@ -508,8 +837,14 @@ def main():
     exchange = None
     if dist is not None:
         from cimg import shard
-        n_items = world * nchunks
-        mine = shard.partition(n_items, world, rank, items_per_group=nchunks)        # rank r owns its own images: items r*nchunks ...
+        per_group = nchunks
+        if strong:
+            n_items = N_image // CHUNK
+            per_group = n_items // CHANNELS
+            mine = shard.partition(n_items, world, rank, items_per_group=per_group)
+        else:
+            n_items = world * nchunks
+            mine = shard.partition(n_items, world, rank, items_per_group=nchunks)    # rank r owns its own images: items r*nchunks ...
         sizes_all = shard.gather_sizes(dist, mine, cbytes, n_items, device=red_dev)
         comp_view = d_comp if not rehearsal else d_comp.cpu()
         xdev = "cpu" if rehearsal else "cuda"
@@ -518,13 +853,13 @@ def main():
             torch.cuda.synchronize()
             tx = time.perf_counter()
             got = shard.gather_chunks(dist, world, rank, mine, comp_view, comp_off, sizes_all, n_items, dst=0,
-                                      items_per_group=nchunks, device=xdev, as_tensor=True)
+                                      items_per_group=per_group, device=xdev, as_tensor=True)
             torch.cuda.synchronize()
             dist.barrier()
             tx = time.perf_counter() - tx
         tmax = torch.tensor([tx], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        moved = int(sizes_all.sum() - sizes_all[shard.partition(n_items, world, 0, nchunks)].sum())
+        moved = int(sizes_all.sum() - sizes_all[shard.partition(n_items, world, 0, per_group)].sum())
         if rank == 0:
             whole, offs, szs = got
             probe = int(mine[0]) if len(mine) else 0
@@ -538,50 +873,98 @@ def main():
         print("bench.py: pixels differ after the timed region", file=sys.stderr)
         sys.exit(3)
 
+    # ---- a measured copy peak beside the 8 TB/s specification, and the OTHER face of the codec (natural family) in the same line ----
+    copy_peak = natural = None
+    headline = args.family == "tiled" and args.filter == "shuffle" and args.codec == "lz4" and args.config == 2 and not strong
+    if rank == 0:
+        copy_peak = measure_copy_peak()
+    if rank == 0 and world == 1 and headline and not os.environ.get("CIMG_BENCH_NO_NATURAL"):
+        nat = np.concatenate([synth.natural_channel(DTYPE, WIDTH, HEIGHT, c=c).view(np.uint8).ravel() for c in range(CHANNELS)])
+        d_raw.copy_(torch.from_numpy(nat).cuda())
+        step(); step()
+        d_out.zero_()
+        torch.cuda.synchronize()
+        eng.enable_timing(1); eng.reset_timing()
+        tn = time.perf_counter()
+        nsteps = 8
+        for _ in range(nsteps):
+            ncb = step()
+        torch.cuda.synchronize()
+        tn = time.perf_counter() - tn
+        ne, nd = eng.kernel_samples(hip.K_ENCODE), eng.kernel_samples(hip.K_DECODE)
+        eng.enable_timing(False)
+        ok = torch.equal(d_out, d_raw)
+        natural = {"what": "the same geometry on the 'natural' family (smooth gradients + noise in every byte plane: what photographs look like; cimg/synth.py), "
+                           f"{nsteps} steps outside the timed region", "value": round(nsteps * 2 * N / tn / 1e9, 3), "unit": "GB/s",
+                   "encode_us": round(float(np.median(ne)) * 1e3, 1) if len(ne) else None, "decode_us": round(float(np.median(nd)) * 1e3, 1) if len(nd) else None,
+                   "compression_ratio": round(N / float(ncb.sum()), 4), "pixels_verified": bool(ok)}
+        d_raw.copy_(torch.from_numpy(host).cuda())
+        torch.cuda.synchronize()
+
     if rank == 0:
         Cb = float(cbytes.sum())
         algo = {hip.K_ENCODE: N + Cb, hip.K_LAYOUT: 0.0, hip.K_EMIT: 0.0, hip.K_DECODE: Cb + N}
+        # the decode entry of the engine's timers covers cimg_decode_lean + whatever cimg_decode_blocks had to do behind it; it is
+        # reported under the kernel that did the work (engine statistics: blocks the lean launch left over)
+        lean_only = dstats["lean_batches"] > 0 and dstats["blocks_left_to_general"] == 0
+        dec_name = "cimg_decode_lean" if lean_only else ("cimg_decode_lean + cimg_decode_blocks" if dstats["lean_batches"] > 0 else "cimg_decode_blocks")
+        enc_name = "cimg_encode_streams" if args.codec == "lz4" else "cimg_encode_streams_blosclz"
+        names = {hip.K_ENCODE: enc_name, hip.K_LAYOUT: "cimg_layout_chunks", hip.K_EMIT: "cimg_emit_blocks", hip.K_DECODE: dec_name}
         kernels = {}
         for k, (ms, n) in enumerate(ktimes):
             avg = ms / n if n else 0.0
-            kernels[hip.KERNELS[k]] = {
-                "launches": n, "avg_us": round(avg * 1e3, 2),
+            med = float(np.median(ksamples[k])) if len(ksamples[k]) else 0.0
+            kernels[names[k]] = {
+                "launches": n, "avg_us": round(avg * 1e3, 2), "median_us": round(med * 1e3, 2),
                 "algorithmic_GBps": round(algo[k] / (avg * 1e-3) / 1e9, 1) if avg > 0 and algo[k] else None}
         dom = max(range(4), key=lambda k: ktimes[k][0])
         dom_avg_s = ktimes[dom][0] / max(ktimes[dom][1], 1) * 1e-3
         achieved = algo[dom] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
         dec_avg_s = ktimes[hip.K_DECODE][0] / max(ktimes[hip.K_DECODE][1], 1) * 1e-3
-        headline = args.family == "tiled" and args.filter == "shuffle" and args.codec == "lz4" and args.config == 2
+        dec_med_s = (float(np.median(ksamples[hip.K_DECODE])) if len(ksamples[hip.K_DECODE]) else 0.0) * 1e-3
         traffic, traffic_src = pmc_traffic(hip.KERNELS[dom], args.pmc_json) if headline else (None, None)
         dec_traffic, _ = pmc_traffic(hip.KERNELS[hip.K_DECODE], args.pmc_json) if headline else (None, None)
+        N_job = N_image if strong else world * N                  # uncompressed bytes one step of the whole job processes
         out = {
             "metric": "compress+decompress GB/s (uncompressed side)" + (" -- INVALID: pixels not verified (CIMG_BENCH_NO_VERIFY)" if no_verify else ""),
-            "value": round(world * args.steps * 2 * N / elapsed / 1e9, 3),
+            "value": round(args.steps * 2 * N_job / elapsed / 1e9, 3),
             "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_median": round(_median(per_step) * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{'BASELINE configs[3] share of one rank: 8 images x ' if args.config == 4 else ''}"
-                                   f"{len(chans)}x{WIDTH}x{HEIGHT} float16 per GPU, {args.codec} clevel 9 + {FILTER_TEXT[args.filter]}, "
+                                   f"{len(chans)}x{WIDTH}x{HEIGHT} float16 {'for the WHOLE job (strong scaling), this rank holds' if strong else 'per GPU'}, "
+                                   f"{args.codec} clevel 9 + {FILTER_TEXT[args.filter]}, "
                                    f"32 KiB blocks, 4 MiB chunks ({nchunks} chunks, {N // BLOCK} blocks, {2 * N // BLOCK} streams), "
                                    f"device-resident, family={args.family}",
                        "element_dtype": "float16", "uncompressed_bytes_per_gpu": N, "compressed_bytes_per_gpu": int(Cb),
                        "compression_ratio": round(world * N / total_c, 4) if total_c else None,
-                       "roundtrip_GBps": round(world * args.steps * N / elapsed / 1e9, 3),
+                       "roundtrip_GBps": round(args.steps * N_job / elapsed / 1e9, 3),
                        "first_call_ms": round(first_call_ms, 3),       # the steady state rides the descriptor cache and warm buffers; this is the cold step
-                       "parallelism": f"chunks sharded by rank x{world}, no data-path collective"},
-            "roofline": {"kernel": hip.KERNELS[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                       "parallelism": (f"strong scaling: ONE image's {N_image // CHUNK} chunks split over {world} rank(s) as cimg/shard.py partition does "
+                                       f"(this rank: {nchunks}), no data-path collective" if strong else
+                                       f"chunks sharded by rank x{world}, no data-path collective"),
+                       "per_rank_kernel_median_us": ({"encode_decode": per_rank_us} if per_rank_us else None)},
+            "roofline": {"kernel": names[dom], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "measured_copy_peak": copy_peak, "frac_of_measured_peak": round(achieved / copy_peak, 4) if copy_peak else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(algo[dom]), "avg_launch_us": round(dom_avg_s * 1e6, 2),
                          "note": ("the launch contains chunk layout + emit (separate kernels until round 2: encode 349 + layout 7 + emit 29 us; "
                                   "CIMG_NO_ASSEMBLE_IN_LAUNCH=1 runs them separately again)") if kernels["cimg_emit_blocks"]["launches"] == 0 and dom == hip.K_ENCODE else None},
-            "roofline_decode": {"kernel": hip.KERNELS[hip.K_DECODE], "bound": "hbm",
+            "roofline_decode": {"kernel": dec_name, "bound": "hbm",
                                 "achieved": round((Cb + N) / dec_avg_s / 1e9, 1) if dec_avg_s > 0 else None,
                                 "output_side": round(N / dec_avg_s / 1e9, 1) if dec_avg_s > 0 else None,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": dec_traffic,
-                                "frac": round((Cb + N) / dec_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if dec_avg_s > 0 else None},
+                                "frac": round((Cb + N) / dec_avg_s / 1e9 / HBM_PEAK_GBPS, 4) if dec_avg_s > 0 else None,
+                                "avg_launch_us": round(dec_avg_s * 1e6, 2), "median_launch_us": round(dec_med_s * 1e6, 2),
+                                "measured_copy_peak": copy_peak,
+                                "frac_of_measured_peak": round((Cb + N) / dec_avg_s / 1e9 / copy_peak, 4) if dec_avg_s > 0 and copy_peak else None},
             "kernels": kernels,
+            "natural_family": natural,
+            "last_step_verified": "d_out cleared in front of the last timed step, pixels compared with the input after it",
             "exchange": exchange,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
             "step_calls": ("cimg_compress_batch_device + cimg_decompress_batch_device (one wait each)" if sync_calls else

@@ -303,6 +303,36 @@ class Engine:
             return cbytes
         return step
 
+    def stream_handle(self):
+        """the engine's hipStream_t as an integer (torch.cuda.ExternalStream(handle) enqueues a caller's own kernels on it)"""
+        return int(load().cimg_engine_stream(self.handle) or 0)
+
+    def single_chunk_calls(self, p, d_work, d_comp, comp_off, chunk_bytes, destsize, blocksize):
+        """get_chunk(i) / set_chunk(i) of a channel whose chunks live at d_comp + comp_off[i] (the random-access loop of the
+        reference's examples/lazy_channels/main.cpp:35-52; channel.h:502-538): one device-resident decompress call of ONE chunk into
+        d_work, one compress call of ONE chunk from d_work back into its slot.  Arguments marshalled once (a per-call numpy -> ctypes
+        conversion costs the host more than a single-chunk launch).  set_chunk returns the chunk's new compressed size."""
+        L = load()
+        comp_off = _i64(comp_off)
+        n = int(comp_off.size)
+        zero = _i64([0]); nb = _i32([chunk_bytes]); ds = _i32([destsize]); bs = _i32([blocksize])
+        cb = np.zeros(1, np.int32); st = np.zeros(1, np.int32)
+        keep = (comp_off, zero, nb, ds, bs, cb, st, p)
+        h, pp = self.handle, C.byref(p)
+        base = comp_off.ctypes.data
+        a_zero, a_nb, a_ds, a_bs, a_cb, a_st = _ptr(zero), _ptr(nb), _ptr(ds), _ptr(bs), _ptr(cb), _ptr(st)
+        vw, vc = C.c_void_p(d_work), C.c_void_p(d_comp)
+        dec, enc, check = L.cimg_decompress_batch_device, L.cimg_compress_batch_device, self._check
+
+        def get_chunk(i, _keep=keep):
+            check(dec(h, 1, vc, C.c_void_p(base + 8 * i), a_nb, a_bs, vw, a_zero, a_st))
+
+        def set_chunk(i, _keep=keep):
+            check(enc(h, pp, 1, vw, a_zero, a_nb, vc, C.c_void_p(base + 8 * i), a_ds, a_cb))
+            return int(cb[0])
+        assert n > 0
+        return get_chunk, set_chunk
+
     # ---- host-resident batches ----
     def compress_host(self, p, raw, nbytes, destsize):
         """raw: numpy array holding the chunks back to back.  Returns list of chunk bytes (b'' = does not fit)."""

@@ -156,6 +156,8 @@ struct cimg_engine {
     bool side_used = false;             // something was launched on s_side since the last synchronize (an error path must not leave it running)
     bool no_side = getenv("CIMG_NO_SIDE_STREAM") != nullptr;   // diagnostic: the two encode launches one behind the other again
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done = nullptr;
+    int64_t host_register_bytes = getenv("CIMG_HOST_REGISTER_MIB") ? atoll(getenv("CIMG_HOST_REGISTER_MIB")) << 20 : 32ll << 20;   // pageable host spans from this size on are page-locked for the call (HostPin); 0: never
+    int64_t host_registrations = 0;
     int64_t host_group_bytes = getenv("CIMG_HOST_GROUP_MIB") ? atoll(getenv("CIMG_HOST_GROUP_MIB")) << 20 : 16ll << 20;   // measured: 8 / 16 / 32 / 64 MiB -> 45.9 / 46.6 / 44.3 / 39.0 GB/s
     DevBuf descs_enc, descs_dec, recs, layout, scratch, stage_raw, stage_comp, stage_il, dbg, queue;
     // chunk descriptors last uploaded for encode / decode: a batch with the same geometry as the previous one
@@ -1070,6 +1072,46 @@ struct Groups {
     int count() const { return (int)first.size() - 1; }
 };
 
+// A caller's PAGEABLE span page-locked for the duration of one batch call (hipHostRegister ... hipHostUnregister): from pageable
+// memory hipMemcpyAsync stages through the runtime's own pinned bounce buffers on the calling thread (31 GB/s combined on
+// configs[1], against 46 from page-locked memory: INTEGRATION.md section 4); a registered span is DMA'd from where it lies.
+// Registering costs time per page, so only spans of at least `host_register_bytes` are registered (CIMG_HOST_REGISTER_MIB; 0 = never);
+// memory that is page-locked already (hipHostMalloc, torch pinned tensors, a span the caller registered) is left alone, and so is
+// everything when the registration fails (the copies then run as before).  Nothing stays registered behind the call: the
+// engine cannot know when the caller frees the buffer.
+struct HostPin {
+    void* base = nullptr;
+    cimg_engine* eng;
+    HostPin(cimg_engine* e, const void* host, const int64_t* off, const int32_t* len, int n, bool writable) : eng(e)
+    {
+        (void)writable;
+        if (!host || n <= 0 || e->host_register_bytes <= 0) return;
+        int64_t lo = INT64_MAX, hi = INT64_MIN, total = 0;
+        for (int i = 0; i < n; i++) {
+            if (len[i] <= 0) continue;
+            lo = std::min(lo, off[i]); hi = std::max(hi, off[i] + (int64_t)len[i]); total += len[i];
+        }
+        if (total < e->host_register_bytes || hi <= lo || (hi - lo) > 2 * total) return;       // (a sparse span would pin what is never copied)
+        const uintptr_t a = ((uintptr_t)host + (uintptr_t)lo) & ~(uintptr_t)4095;
+        const uintptr_t b = (((uintptr_t)host + (uintptr_t)hi) + 4095) & ~(uintptr_t)4095;
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, (const void*)a) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;   // page-locked already
+        (void)hipGetLastError();
+        if (hipHostRegister((void*)a, (size_t)(b - a), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        base = (void*)a;
+        e->host_registrations++;
+    }
+    ~HostPin()
+    {
+        if (!base) return;
+        // (every regular return has waited for its copies; an error return in the middle of a pipeline may not have)
+        (void)hipStreamSynchronize(eng->s_h2d); (void)hipStreamSynchronize(eng->s_d2h); (void)hipStreamSynchronize(eng->stream);
+        (void)hipHostUnregister(base);
+    }
+    HostPin(const HostPin&) = delete;
+    HostPin& operator=(const HostPin&) = delete;
+};
+
 // host -> device copy of chunks [a, b): one transfer when they are contiguous on both sides
 int copy_in(cimg_engine* e, hipStream_t st, uint8_t* dev, const int64_t* dev_off, const uint8_t* host, const int64_t* host_off,
             const int32_t* len, int a, int b, const char* what)
@@ -1135,6 +1177,7 @@ int compress_host_pipeline(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     uint8_t* sr = (uint8_t*)e->stage_raw.p;
     uint8_t* sc = (uint8_t*)e->stage_comp.p;
     const int ng = G.count();
+    HostPin pin_raw(e, h_raw, raw_off, nbytes, nchunks, false);       // (released when this function returns: every copy has been waited for)
     if (ng == 1) {
         // a small batch (the blosc2_compress_ctx shim: one chunk) has nothing to overlap: one stream, no events
         if ((rc = copy_in(e, e->stream, sr, d_raw_off.data(), hr, raw_off, nbytes, 0, nchunks, "pixels H2D"))) return rc;
@@ -1313,6 +1356,7 @@ int cimg_decompress_batch_host_sized(cimg_engine* e, int32_t nchunks, const void
     uint8_t* sr = (uint8_t*)e->stage_raw.p;
     uint8_t* sc = (uint8_t*)e->stage_comp.p;
     uint8_t* hr = (uint8_t*)h_raw;
+    HostPin pin_out(e, h_raw, raw_off, nb.data(), nchunks, true);     // the pixels' destination (every return path below has waited for its copies)
     std::vector<int32_t> st((size_t)nchunks, 0);
     std::vector<int32_t> deliver((size_t)nchunks, 0);
     if (ng == 1) {
