@@ -49,6 +49,10 @@ struct DecodeArgs {
     // chunk k -- the leftover blocks the lean kernel never takes, one workgroup per chunk.  cimg_decode_lean: blk_first != 0 says
     // that launch exists, and leftover blocks are then not counted in `skipped`.
     int32_t blk_first, blk_step;
+    // cimg_decode_lean: how two waves that share a SIMD are kept from running their chains in lockstep (engine.hip: lean_tune;
+    // decode_lean_kernel.h: run) -- bits 0-7: the younger wave of a SIMD starts n x 64 cycles late; bit 8: from its second block on
+    // the younger wave runs at raised priority
+    int32_t tune;
 };
 
 CIMG_HD int round16(int x) { return (x + 15) & ~15; }

@@ -261,7 +261,11 @@ struct DecodeLeanWave {
                         u128 o;
                         o.x = byte_perm(hi0, lo0, 0x05010400u); o.y = byte_perm(hi0, lo0, 0x07030602u);
                         o.z = byte_perm(hi1, lo1, 0x05010400u); o.w = byte_perm(hi1, lo1, 0x07030602u);
+#ifdef CIMG_ABL_NO_STORE      /* timing experiment only (tools/diag_dectime.py): the block's pixels are not written */
+                        if (o.x == 0x12345678u && o.y == 0x9abcdef0u && o.z == 1u && o.w == 2u) st128u(out + 2 * off8, o);
+#else
                         st128u(out + 2 * off8, o);
+#endif
                     }
                 }
             }
@@ -363,6 +367,12 @@ struct DecodeLeanWave {
     {
         LeanHead cur, nxt, far;
         LeanBody body, nbody;
+        // (DecodeArgs::tune -- only where waves are persistent and start together: a launch of one workgroup per block has its
+        // waves starting whenever a slot falls free)
+        const int tune = G < a.total_blocks ? a.tune : 0;
+        const int slot = tune ? wave_slot() : 0;
+        if ((tune & 0xFF) && (tune & 0x10000)) wave_sleep64((tune & 0xFF) * (2 * wave_simd() + (slot & 1)));      // every wave of a CU its own delay
+        else if ((tune & 0xFF) && (slot & 1)) wave_sleep64(tune & 0xFF);
         issue_head(cur, w);
         issue_head(nxt, w + G);
         finish_head(cur);
@@ -374,9 +384,14 @@ struct DecodeLeanWave {
             finish_head(nxt);                           // block i + 1: its header arrived during the previous chain ...
             issue_body(nbody, nxt);                     // ... its size words and coded bytes are requested now
             issue_head(far, b + 2 * G);                 // block i + 2: descriptor, header, bstarts[j]
+#ifdef CIMG_ABL_NO_CHAIN      /* timing experiment only: the coded plane is not decoded */
+            if (ok) unshuffle(b);
+#else
             if (ok && chain(cur)) unshuffle(b);
+#endif
             else if (!(cur.leftover_blk && a.blk_first)) leave();      // (a.blk_first != 0: the leftover blocks are launched separately, nobody counts them)
             LEAN_STAMP(a.dbg, b, 3);
+            if ((tune & 0x100) && (slot & 1) && guard == 0) wave_priority(tune >> 9 & 3);
             cur = nxt; body = nbody; nxt = far;
         }
         if (a.skipped && left) { const uint32_t v = (uint32_t)left; FOR_LANES_W(l) { if (l == 0) a.skipped[w] = v; } }

@@ -186,6 +186,11 @@ struct cimg_engine {
     int lean_wgs_cu = 0, lean_wgs_lds = -1;   // resident lean decode waves per CU for that much LDS (occupancy query, cached)
     int lean_wgs_limit = getenv("CIMG_LEAN_WGS_PER_CU") ? atoi(getenv("CIMG_LEAN_WGS_PER_CU")) : 0;   // diagnostic: fewer persistent waves
     uint32_t done_gen = 0;
+    // DecodeArgs::tune.  Two lean waves share a SIMD, the issue arbiter serves the older first, and in the first round -- every wave
+    // of the CU in the same phase of the same code -- the younger one pays for it (tools/diag_stamps_hw.py: first block 22 us in the
+    // older slot, 27 in the younger; later blocks 21 / 22).  Default: every wave of a CU starts (2 x simd + slot) x 16 x 64 cycles
+    // late, and the younger wave runs its later blocks at raised priority: 66 -> 64 us on configs[1] (0: off).
+    int lean_tune = getenv("CIMG_LEAN_TUNE") ? atoi(getenv("CIMG_LEAN_TUNE")) : (0x10000 | 0x100 | (3 << 9) | 16);
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
     int64_t zstd_batches = 0;           // decode batches that needed cimg_decode_zstd
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
@@ -899,7 +904,7 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
             memset((void*)skipped_host, 0, sizeof(uint32_t) * (size_t)grid);        // a wave only writes its word if it left blocks over
             e->dflight.lean_grid = grid;
             DecodeArgs la{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_lean, dbg,
-                          plan.uniform_nblocks, done, e->done_gen, skipped_dev, plan.total_blocks, known_left ? 1 : 0, 1};   // (blk_first here: leftover blocks are not counted)
+                          plan.uniform_nblocks, done, e->done_gen, skipped_dev, plan.total_blocks, known_left ? 1 : 0, 1, e->lean_tune};   // (blk_first here: leftover blocks are not counted)
             rc = e->launch(CIMG_K_DECODE, cimg_decode_lean, la, grid, 64, plan.lds_lean);
         }
     }
@@ -908,7 +913,7 @@ static int decompress_launch(cimg_engine* e, int32_t nchunks, const void* d_comp
     const bool general_now = !lean || e->lean_last_skipped != 0;
     // (diagnostic stamps go to the lean launch when there is one: both would write the same slots)
     DecodeArgs da{(const ChunkDesc*)e->descs_dec.p, nchunks, (const uint8_t*)d_comp, (uint8_t*)d_raw, st_dev, plan.lds_bytes, (lean && stamping) ? nullptr : dbg,
-                  plan.uniform_nblocks, done, e->done_gen, nullptr, plan.total_blocks, 0, 1};
+                  plan.uniform_nblocks, done, e->done_gen, nullptr, plan.total_blocks, 0, 1, 0};
     if (!rc && general_now) {
         if (!(rc = e->allow_lds(cimg_decode_blocks, 1, plan.lds_bytes)))
             rc = e->launch(CIMG_K_DECODE, cimg_decode_blocks, da, plan.total_blocks, 256, plan.lds_bytes);

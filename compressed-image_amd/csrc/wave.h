@@ -83,6 +83,10 @@ inline void wave_exscan(const LV<int>& x, LV<int>& out, int& total)
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
 inline void debug_stamp(uint64_t*, int, int) {}
+inline int wave_slot() { return 0; }
+inline int wave_simd() { return 0; }
+inline void wave_priority(int) {}
+inline void wave_sleep64(int) {}
 template <class T> inline void writelane(LV<T>& x, int lane, T value) { x.v[lane & 63] = value; }
 template <class T> inline void lane_gather(const LV<T>& x, const LV<int>& idx, LV<T>& out)
 {
@@ -273,6 +277,23 @@ CIMG_DEV unsigned long long cimg_realtime()
     unsigned long long t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
     return t;
+}
+// the wave's slot on its SIMD (HW_ID.wave_id): waves that share a SIMD have different slots; the lower slot is the older wave,
+// and the issue arbiter serves the oldest wave first
+CIMG_DEV int wave_slot() { return (int)__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (3 << 11)); }
+CIMG_DEV int wave_simd() { return (int)__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (4 << 6) | (1 << 11)); }
+// s_setprio takes an immediate
+CIMG_DEV void wave_priority(int p)
+{
+    if (p <= 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// n x 64 cycles of s_sleep (n wave-uniform, at most a few hundred)
+CIMG_DEV void wave_sleep64(int n)
+{
+    for (int i = 0; i < n && i < 1024; i += 8) __builtin_amdgcn_s_sleep(8);
 }
 // diagnostic builds only (dbg != nullptr): slot[16*w + 4*which], which = 0..3 = {shader clock, 100 MHz wall clock | hw id}
 CIMG_DEV void debug_stamp(uint64_t* dbg, int w, int which)
