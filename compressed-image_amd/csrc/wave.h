@@ -40,6 +40,12 @@ template <class T> using kernarg_ptr = const T*;
 template <class T> inline kernarg_ptr<T> fresh(kernarg_ptr<T> p) { return p; }
 #define CIMG_OWN_KERNARGS(T, passed) (passed)
 typedef volatile uint16_t* cimg_lds_vu16p;
+typedef const uint32_t* cimg_lds_cu32p;
+typedef const uint8_t* cimg_lds_cu8p;
+typedef const uint16_t* cimg_lds_cu16p;
+#define CIMG_AS_LDS_CU16(p) ((const uint16_t*)(p))
+#define CIMG_AS_LDS_CU32(p) ((const uint32_t*)(p))
+#define CIMG_AS_LDS_CU8(p) ((const uint8_t*)(p))
 #define CIMG_AS_LDS_VU16(p) (reinterpret_cast<volatile uint16_t*>(p))
 
 namespace cimg {
@@ -163,6 +169,15 @@ template <class T> __device__ __forceinline__ kernarg_ptr<T> kernarg_scalar_agai
 // (slow, and not ordered with ds_* ops): LDS pointers that must be volatile carry the address space explicitly
 typedef volatile __attribute__((address_space(3))) uint16_t* cimg_lds_vu16p;
 #define CIMG_AS_LDS_VU16(p) ((cimg_lds_vu16p)(p))
+// read-only LDS data behind a pointer the compiler can no longer trace to the __shared__ array (it went through a struct in memory,
+// or a select between an LDS and a global address): as a generic pointer every access is a FLAT load -- several hundred cycles and
+// a vmcnt wait each -- so the hot loops that KNOW where their tables lie say so
+typedef const __attribute__((address_space(3))) uint32_t* cimg_lds_cu32p;
+typedef const __attribute__((address_space(3))) uint8_t* cimg_lds_cu8p;
+typedef const __attribute__((address_space(3))) uint16_t* cimg_lds_cu16p;
+#define CIMG_AS_LDS_CU16(p) ((cimg_lds_cu16p)(p))
+#define CIMG_AS_LDS_CU32(p) ((cimg_lds_cu32p)(p))
+#define CIMG_AS_LDS_CU8(p) ((cimg_lds_cu8p)(p))
 
 namespace cimg {
 

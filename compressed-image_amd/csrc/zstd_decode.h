@@ -15,6 +15,7 @@
 #include "codec_types.h"
 #include "wave.h"
 #include <cstring>
+#include <type_traits>
 
 namespace cimg {
 
@@ -31,6 +32,18 @@ struct ZstdWork {
     uint8_t weights[256];
     int32_t ll_log, ml_log, of_log, huf_log, have_huf, have_tables;
     int32_t rank_count[ZSTD_HUF_LOG_MAX + 2], rank_idx[ZSTD_HUF_LOG_MAX + 2];
+    // the memory around the output that may be READ with aligned dword loads (both 4-byte aligned; zstd_execute_batch fetches 16
+    // bytes of a copy's source with five of them and never reads outside): the kernel's whole LDS; exactly the output buffer in
+    // the host tests.  nullptr: every copy goes the byte-exact serial way.
+    const uint8_t* mem_lo;
+    const uint8_t* mem_hi;
+    // the sequences section of the block being decoded: arguments and results of zstd_sequences (an out-of-line function reads its
+    // arguments here instead of taking a dozen of them through vector registers)
+    const uint8_t* seq_bs;   // the bit stream and its length; seq_bs_lds: it lies in LDS (the stage, or a frame staged whole)
+    uint8_t* seq_dst;        // the frame's output
+    const uint8_t* seq_lit;  // the block's literals
+    int32_t seq_bl, seq_bs_lds, seq_nseq, seq_dcap, seq_dpos, seq_regen, seq_lpos;
+    int32_t r0, r1, r2;      // the frame's repeat offsets
     int32_t tail;            // 1: the frame lies in global memory -- the section being decoded is copied to `stage` when it fits there
     int32_t stage_cap;       // bytes at stage
     uint8_t* stage;          // 16-byte aligned
@@ -306,6 +319,149 @@ CIMG_DEV int zstd_huf_stream(const uint8_t* src, int size, uint8_t* out, int cou
 // position, state and output quarter in its own registers, table reads and literal stores at its own LDS addresses.  One round
 // of the loop costs what one literal costs the scalar form (measured: 460 cycles, a dependent LDS read and some thirty
 // instructions) and yields four.  The checks are those of the scalar form, per lane.
+// The same loop through LDS-typed pointers (round 4): as generic pointers every table read and every refill of the bits was a FLAT
+// load, and streams that did not fit the stage were read from GLOBAL memory bit by bit (the natural family: 21 KiB of coded
+// literals per block against an 8 KiB stage -- 740 cycles a round).  Here each of the four lanes keeps 64 bits of its stream in a
+// register pair, refilled with one 8-byte LDS read about every fifth symbol, and reads the table through an address-space-3
+// pointer.  The streams are seen through WINDOWS: lane k's LDS bytes at win + k * wstride are bytes [a_k, a_k + wlen_k) of its stream.
+// Streams that lie in LDS whole are one window each (a = 0); streams in global memory travel through the stage a quarter of
+// it at a time, from their ends downwards (they are read backwards), and the loop returns 1 when a lane needs bytes below its
+// window -- nothing of that symbol is consumed -- for the caller to move the windows and call again.  Checks and results as below.
+struct ZstdHuf4 {
+    LV<int> size, count, obase, top, state, n, lo, a;      // per lane (lanes 0 .. 3 are the streams)
+    LV<uint32_t> c0, c1;                                   // bits [lo, lo + 64) of the lane's stream
+    bool primed = false;
+};
+template <class BP, class HP>
+CIMG_DEV int zstd_huf4_run(ZstdHuf4& h, BP win, int wstride, uint8_t* out, int per, int last, HP huf, int log)
+{
+    const int mask = (1 << log) - 1;
+    LV<bool> starve;
+    FOR_LANES(l) { starve[l] = false; }
+    // nb bits below `top` of the lane's stream (top moves down by nb); bits below position 0 read as zero.  `starve`: the bytes
+    // lie below the lane's window -- nothing is consumed
+    auto take = [&](int l, int nb) -> uint32_t {
+        const int t = h.top[l] - nb;
+        if (nb <= 0) { h.top[l] = t; return 0u; }
+        const BP sp = win + (l & 3) * wstride - h.a[l];    // (sp[i] = byte i of the stream, for i inside the window)
+        if (h.size[l] >= 8 && t >= 0) {
+            if (h.lo[l] < 0 || t < h.lo[l]) {
+                const int b = ((t + nb + 7) >> 3) - 8;
+                const int b0 = b > 0 ? b : 0;
+                if (b0 < h.a[l]) { starve[l] = true; return 0u; }
+                h.lo[l] = 8 * b0;
+                // eight bytes from any address: three aligned dwords and two funnel shifts (an unaligned 8-byte read of LDS is
+                // taken apart into byte reads by the compiler)
+                // (the host build reads exactly eight bytes: its buffers end where the streams end)
+#ifdef CIMG_EMULATE
+                uint64_t c;
+                __builtin_memcpy(&c, sp + b0, 8);
+                h.c0[l] = (uint32_t)c; h.c1[l] = (uint32_t)(c >> 32);
+#else
+                const BP q = sp + b0;
+                const uint32_t sh = (uint32_t)((uintptr_t)q & 3u);
+                using WP = typename std::conditional<std::is_same<BP, const uint8_t*>::value, const uint32_t*, cimg_lds_cu32p>::type;
+                const WP wp = (WP)(q - sh);
+                const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                h.c0[l] = alignbyte(w1, w0, sh); h.c1[l] = alignbyte(w2, w1, sh);
+#endif
+            }
+            h.top[l] = t;
+            const uint64_t cc = ((uint64_t)h.c1[l] << 32) | h.c0[l];
+            return (uint32_t)(cc >> (t - h.lo[l])) & (uint32_t)((1u << nb) - 1);
+        }
+        // (the rare path, byte by byte: streams shorter than eight bytes, and the last reads of a stream)
+        if (h.a[l] > 0) { starve[l] = true; return 0u; }     // (only reached near the start of a stream: its window must begin there)
+        h.top[l] = t;
+        uint64_t acc = 0;
+        int bit = t, miss = 0;
+        if (bit < 0) { miss = -bit; bit = 0; }
+        if (miss >= nb) return 0u;
+        for (int q = 0; q < 5; q++) {
+            const int bq = (bit >> 3) + q;
+            const uint64_t v = (bq >= 0 && bq < h.size[l]) ? (uint64_t)sp[bq] : 0;
+            acc |= v << (8 * q);
+        }
+        return (uint32_t)((acc >> (bit & 7)) & ((1ull << (nb - miss)) - 1)) << miss;
+    };
+    LV<bool> act, bad;
+    FOR_LANES(l) { act[l] = l < 4; }
+    if (!h.primed) {
+        FOR_LANES(l) { if (act[l]) h.state[l] = (int)take(l, log); }
+        if (ballot(starve)) return 1;                        // (cannot happen: the first windows end at the ends of the streams)
+        h.primed = true;
+    }
+    for (int guard = 0; guard <= (per > last ? per : last) + 1; ++guard) {
+        LV<bool> go;
+        FOR_LANES(l) { go[l] = act[l] & (h.top[l] > -log); }
+        if (!ballot(go)) break;
+        FOR_LANES(l) { bad[l] = go[l] & (h.n[l] >= h.count[l]); }
+        if (ballot(bad)) return ERR_DATA;
+        FOR_LANES_W(l) {
+            if (go[l]) {
+                const uint32_t e = huf[h.state[l] & mask];
+                const int nb = (int)(e >> 8);
+                const uint32_t bits = take(l, nb);
+                if (!starve[l]) {
+                    out[h.obase[l] + h.n[l]] = (uint8_t)e;
+                    h.state[l] = ((h.state[l] << nb) + (int)bits) & mask;
+                    h.n[l] += 1;
+                }
+            }
+        }
+        if (ballot(starve)) return 1;
+    }
+    FOR_LANES(l) { bad[l] = act[l] & ((h.top[l] != -log) | (h.n[l] != h.count[l])); }
+    return ballot(bad) ? ERR_DATA : 0;
+}
+
+CIMG_DEV void zstd_stage(uint8_t* dst, const uint8_t* src, int n);
+
+// the four streams of a literals section at ls (sizes z0 .. z3).  in_lds: they lie in LDS (the stage, or a frame staged whole);
+// else they are brought through w->stage, a quarter of it per stream and window
+template <class HP>
+CIMG_DEV int zstd_huf_stream4_lds(const uint8_t* ls, bool in_lds, int z0, int z1, int z2, int z3, uint8_t* out, int per, int last, HP huf, int log, const ZstdWork* w)
+{
+    ZstdHuf4 h;
+    LV<int> base;
+    LV<bool> bad;
+    FOR_LANES(l) {
+        const int k = l & 3;
+        base[l] = k == 0 ? 0 : k == 1 ? z0 : k == 2 ? z0 + z1 : z0 + z1 + z2;
+        h.size[l] = k == 0 ? z0 : k == 1 ? z1 : k == 2 ? z2 : z3;
+        h.count[l] = k == 3 ? last : per;
+        h.obase[l] = k * per;
+        h.n[l] = 0; h.lo[l] = -1; h.c0[l] = 0; h.c1[l] = 0; h.a[l] = 0; h.state[l] = 0;
+        const int lastb = h.size[l] >= 1 ? (int)ls[base[l] + h.size[l] - 1] : 0;
+        bad[l] = (l < 4) & (lastb == 0);
+        h.top[l] = h.size[l] * 8 - (8 - zstd_highbit((uint32_t)(lastb | 1)));     // (| 1: keep the arithmetic defined for a bad stream)
+    }
+    if (ballot(bad)) return ERR_DATA;
+    if (in_lds) {
+        // one window per stream: stream k begins at ls + base_k, i.e. "stride" is not constant -- the four windows are given one
+        // after the other by shifting a_k instead: byte i of stream k lies at ls + base_k + i = win + k * 0 - (-(base_k)) + i
+        FOR_LANES(l) { h.a[l] = -base[l]; }
+        // (a negative a never starves: b0 >= 0 > a)
+        return zstd_huf4_run(h, (cimg_lds_cu8p)CIMG_AS_LDS_CU8(ls), 0, out, per, last, huf, log);
+    }
+    const int W = (w->stage_cap / 4) & ~15;                  // bytes of stage per stream
+    if (W < 64) return -1000;                                // (no stage to speak of: the caller takes the generic loop)
+    for (int round = 0; round < 4096; ++round) {
+        // windows: stream k's bytes [a_k, b_k), b_k just above the byte its reader stands in, at stage + k * W
+        for (int k = 0; k < 4; ++k) {
+            const int topk = readlane(h.top, k), sizek = readlane(h.size, k), basek = readlane(base, k);
+            int bk = ((topk > 0 ? topk : 0) + 7) / 8 + 1;
+            if (bk > sizek) bk = sizek;
+            const int ak = bk > W ? bk - W : 0;
+            zstd_stage(w->stage + k * W, ls + basek + ak, bk - ak);
+            FOR_LANES(l) { if (l == k) { h.a[l] = ak; h.lo[l] = -1; } }
+        }
+        const int rc = zstd_huf4_run(h, (cimg_lds_cu8p)CIMG_AS_LDS_CU8(w->stage), W, out, per, last, huf, log);
+        if (rc != 1) return rc;
+    }
+    return ERR_DATA;
+}
+
 CIMG_DEV int zstd_huf_stream4(const uint8_t* ls, int z0, int z1, int z2, int z3, uint8_t* out, int per, int last, const ZstdWork* w)
 {
     const int log = w->huf_log, mask = (1 << log) - 1;
@@ -397,6 +553,307 @@ CIMG_DEV void zstd_stage(uint8_t* dst, const uint8_t* src, int n)
     FOR_LANES_W(l) { if (done + l < n) dst[done + l] = src[done + l]; }
 }
 
+// ---- up to 64 decoded sequences, executed by the wave (round 4) ------------------------------------------------------------
+// Until round 3 every sequence was decoded AND executed in turn: two wave-wide byte copies (literals, match) per sequence, each a
+// dependent LDS round trip with masked byte stores -- half of a sequence's 2300 cycles, for copies of a dozen bytes (libzstd at
+// level 22 on shuffled float planes: 1856 sequences per 32 KiB block, 5.6 literal and 12 match bytes each).  Now the scalar
+// entropy loop only fills lanes -- lane k holds (literal length, match length, offset) of sequence k, repeat offsets resolved --
+// and this function executes the batch lane-parallel:
+//   * output and literal positions by two prefix sums; all bounds checks at once;
+//   * literals: every lane fetches the first 16 bytes of its run (all loads before any store: a run's destination may overlap
+//     the unread literals of the runs in front of it -- they sit at the end of the output area, zstd_block), runs longer than that
+//     are finished one after the other in sequence order by the whole wave, then every lane stores its first bytes;
+//   * matches, in rounds: with F = the destination of the first match not yet done, every match of at most 16 bytes that does
+//     not overlap itself (or is a byte fill, offset 1) and whose source ends in front of F -- or lies in its own literals -- reads
+//     only finished output: one lane per match, all of them in one step; when only the first pending match is left to do (long,
+//     self-overlapping, or next to unreadable memory) the whole wave copies it the old way.
+// Same checks, same results as the serial loop, also on damaged frames (tests/emu runs both on the same streams).
+CIMG_DEV u128 zstd_fetch16(const uint8_t* p)
+{
+    const uintptr_t a = (uintptr_t)p & ~(uintptr_t)3;
+    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a);
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    u128 r;
+    r.x = alignbyte(q1, q0, sh); r.y = alignbyte(q2, q1, sh); r.z = alignbyte(q3, q2, sh); r.w = alignbyte(q4, q3, sh);
+    return r;
+}
+// the first n (0 .. 16) bytes of v to d: whole dwords, then the last 0 .. 3 bytes
+CIMG_DEV void zstd_store_upto16(uint8_t* d, const u128& v, int n)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    CIMG_UNROLL
+    for (int j = 0; j < 4; j++) { if (n >= 4 * j + 4) lds_st32u(d + 4 * j, w[j]); }
+    const int t = n > 0 ? (n > 16 ? 16 : n) & ~3 : 0;
+    const uint32_t last = t < 16 ? w[(t >> 2) & 3] : 0;
+    CIMG_UNROLL
+    for (int k = 0; k < 3; k++) { if (n > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+}
+
+CIMG_DEV void zstd_copy(uint8_t* dst, const uint8_t* src, int n);
+CIMG_DEV void zstd_match(uint8_t* dst, int offset, int n);
+
+CIMG_DEV int zstd_execute_batch(uint8_t* dst, int dcap, int* dpos_io, const uint8_t* lit, int regen, int* lpos_io, int nb,
+                                const LV<int>& vll, const LV<int>& vml, const LV<int>& vof, const ZstdWork* w)
+{
+    const int dpos = *dpos_io, lpos = *lpos_io;
+    LV<int> len, opos, lsum, ll, ml, of;
+    LV<bool> act;
+    FOR_LANES(l) {
+        act[l] = l < nb;
+        ll[l] = act[l] ? vll[l] : 0; ml[l] = act[l] ? vml[l] : 0; of[l] = act[l] ? vof[l] : 1;
+        len[l] = ll[l] + ml[l];
+    }
+    // (a length that would overflow the sums below cannot belong to a frame that fits: refused before it is added up)
+    LV<bool> bad;
+    FOR_LANES(l) { bad[l] = act[l] & ((ll[l] < 0) | (ml[l] < 0) | (ll[l] > regen) | (ml[l] > dcap)); }
+    if (ballot(bad)) return ERR_DATA;
+    int acc, ltot;
+    wave_exscan(len, opos, acc);
+    wave_exscan(ll, lsum, ltot);
+    if (ltot > regen - lpos || acc > dcap - dpos) return ERR_DATA;
+    LV<int> D, M;
+    FOR_LANES(l) {
+        D[l] = dpos + opos[l];                               // where the literals of the sequence go
+        M[l] = D[l] + ll[l];                                 // where its match goes
+        bad[l] = act[l] & ((of[l] <= 0) | (of[l] > M[l]));   // (the serial loop: offset > dpos once the literals are out)
+    }
+    if (ballot(bad)) return ERR_DATA;
+    const uint8_t* const mlo = w->mem_lo;
+    const uint8_t* const mhi = w->mem_hi;
+#ifdef CIMG_ABL_ZSTD_NO_EXEC      /* timing experiment only: nothing is copied */
+    *dpos_io = dpos + acc; *lpos_io = lpos + ltot;
+    if (acc >= 0) return 0;
+#endif
+    // ---- literals
+    {
+        LV<u128> first;
+        LV<bool> fast, slow;
+        FOR_LANES(l) {
+            const uint8_t* sp = lit + lpos + lsum[l];
+            const uintptr_t a = (uintptr_t)sp & ~(uintptr_t)3;
+            fast[l] = act[l] & (ll[l] > 0) & (mlo != nullptr) & (a >= (uintptr_t)mlo) & (a + 20 <= (uintptr_t)mhi);
+            slow[l] = act[l] & (ll[l] > 0) & !fast[l];
+            if (mlo != nullptr) first[l] = zstd_fetch16(fast[l] ? sp : mlo);          // (a lane that is not fast fetches from mem_lo and drops it)
+            else { first[l].x = 0; first[l].y = 0; first[l].z = 0; first[l].w = 0; }
+        }
+        // runs with more than 16 bytes (and runs next to unreadable memory: whole) in sequence order, by the whole wave
+        LV<bool> longer;
+        FOR_LANES(l) { longer[l] = slow[l] | (fast[l] & (ll[l] > 16)); }
+        uint64_t todo = ballot(longer);
+        const uint64_t whole = ballot(slow);
+        while (todo) {
+            const int t = ctz64(todo);
+            todo &= todo - 1;
+            const int n = readlane(ll, t), d = readlane(D, t), sp = lpos + readlane(lsum, t);
+            const int skip = ((whole >> t) & 1) ? 0 : 16;
+            zstd_copy(dst + d + skip, lit + sp + skip, n - skip);
+        }
+        FOR_LANES_W(l) { if (fast[l]) zstd_store_upto16(dst + D[l], first[l], ll[l] < 16 ? ll[l] : 16); }
+    }
+    // ---- matches
+    uint64_t pending;
+    {
+        LV<bool> has;
+        FOR_LANES(l) { has[l] = act[l] & (ml[l] > 0); }
+        pending = ballot(has);
+    }
+    for (int round = 0; round < 64 && pending; ++round) {
+        const int t0 = ctz64(pending);
+        const int F = readlane(M, t0);
+        LV<bool> ready;
+        FOR_LANES(l) {
+            const int S = M[l] - of[l];
+            const bool fill = of[l] == 1;
+            const uintptr_t a = (uintptr_t)(dst + S) & ~(uintptr_t)3;
+            const bool readable = (mlo != nullptr) & (a >= (uintptr_t)mlo) & (a + 20 <= (uintptr_t)mhi);
+            const bool apart = (of[l] >= ml[l]) | fill;                                    // does not read what it writes (a fill reads one byte)
+            const bool done_src = (S + (fill ? 1 : ml[l]) <= F) | ((S >= D[l]) & (of[l] >= ml[l]));   // finished output, or its own literals
+            ready[l] = ((pending >> l) & 1) & (ml[l] <= 16) & apart & done_src & readable;
+        }
+        const uint64_t rmask = ballot(ready);
+        if (rmask) {
+            LV<u128> v;
+            FOR_LANES(l) {
+                const int S = M[l] - of[l];
+                v[l] = zstd_fetch16(ready[l] ? dst + S : mlo);                              // (rmask != 0: there is a readable range)
+                if (of[l] == 1) { const uint32_t f = (v[l].x & 0xFF) * 0x01010101u; v[l].x = f; v[l].y = f; v[l].z = f; v[l].w = f; }
+            }
+            FOR_LANES_W(l) { if (ready[l]) zstd_store_upto16(dst + M[l], v[l], ml[l]); }
+            pending &= ~rmask;
+        } else {
+            // the first pending match: all output in front of it is final
+            zstd_match(dst + F, readlane(of, t0), readlane(ml, t0));
+            pending &= pending - 1;
+        }
+    }
+    if (pending) return ERR_FAILURE;                         // (cannot happen: every round retires at least one match)
+    *dpos_io = dpos + acc;
+    *lpos_io = lpos + ltot;
+    return 0;
+}
+
+// ---- the sequences section of one block (round 4: out of line, tables and bit stream through LDS-typed pointers) ------------
+// Until round 3 this loop was part of zstd_block, inlined into a kernel of ten thousand instructions: 197 spilled scalars, and --
+// because the work area reaches it through a pointer the compiler cannot trace to the __shared__ array -- every table entry and
+// every refill of the bit container a FLAT load (several hundred cycles and a vmcnt wait, three to four per sequence): 1950 cycles a
+// sequence before a single byte was copied.  Here: a function of its own (its registers are its own), the three tables behind
+// address-space-3 pointers (BP = cimg_lds_cu8p: the bit stream too, which is nearly always in the stage), the next sequence's
+// table entries requested as soon as the states are known, and the sequences handed to zstd_execute_batch 64 at a time.
+// bits [bit, bit + n) of a stream, byte by byte, bytes outside [0, size) read as zero; bit may be negative (the reader's rare path:
+// streams shorter than eight bytes, and the last reads of a stream, which may reach below its first bit)
+template <class BP> CIMG_DEV_OUTLINE uint32_t zstd_bits_slow(BP src_in, int size_in, int bit_in, int n_in)
+{
+    const BP src = (BP)reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>((const uint8_t*)src_in)));
+    const int size = uni(size_in), n = uni(n_in);
+    int bit = uni(bit_in);
+    int miss = 0;
+    if (bit < 0) { miss = -bit; bit = 0; }
+    if (miss >= n) return 0;
+    uint64_t acc = 0;
+    const int b0 = bit >> 3;
+    for (int k = 0; k < 5; k++) {
+        const int b = b0 + k;
+        const uint64_t v = (b >= 0 && b < size) ? (uint64_t)uni((uint32_t)src[b]) : 0;
+        acc |= v << (8 * k);
+    }
+    return (uint32_t)((acc >> (bit & 7)) & ((1ull << (n - miss)) - 1)) << miss;
+}
+template <class BP> struct ZstdBits {                     // the backward bit reader (ZstdBack) on a typed pointer, 32-bit positions
+    BP src;
+    int size, off, lo;                                    // cont holds bits [lo, lo + 64); lo < 0: nothing loaded yet
+    uint64_t cont;
+    CIMG_DEV void init(BP s, int n, int o) { src = s; size = n; off = o; lo = -1; cont = 0; }
+    CIMG_DEV uint32_t get(int n)
+    {
+        if (n <= 0) return 0;
+        const int t = off - n;
+        off = t;
+        if (size >= 8 && t >= 0) {
+            if (lo < 0 || t < lo) {
+                const int b = ((t + n + 7) >> 3) - 8;
+                lo = 8 * (b > 0 ? b : 0);
+                uint64_t c;
+                __builtin_memcpy(&c, src + (lo >> 3), 8);
+                cont = (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
+            }
+            return (uint32_t)(cont >> (t - lo)) & (uint32_t)((1ull << n) - 1);
+        }
+        return uni(zstd_bits_slow<BP>(src, size, t, n));   // (uni: what a real call returns arrives in a vector register)
+    }
+    // the same without the range checks: for callers that know size >= 8 and that off stays >= 0 (zstd_sequences: far from the
+    // start of the stream); n may be 0
+    CIMG_DEV uint32_t getf(int n)
+    {
+        const int t = off - n;
+        if (t < lo || lo < 0) {
+            lo = 8 * (((off + 7) >> 3) - 8);
+            uint64_t c;
+            __builtin_memcpy(&c, src + (lo >> 3), 8);
+            cont = (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
+        }
+        off = t;
+        return (uint32_t)(cont >> (t - lo)) & (uint32_t)((1ull << n) - 1);
+    }
+};
+// length codes above the directly coded ones (literal lengths from 16, match lengths from 35): (base << 8) | extra bits
+CIMG_DEV_OUTLINE uint32_t zstd_ll_code_slow(int c_in) { const int c = uni(c_in); return ((uint32_t)zstd_ll_base(c) << 8) | (uint32_t)zstd_ll_bits(c); }
+CIMG_DEV_OUTLINE uint32_t zstd_ml_code_slow(int c_in) { const int c = uni(c_in); return ((uint32_t)zstd_ml_base(c) << 8) | (uint32_t)zstd_ml_bits(c); }
+
+CIMG_DEV int32_t zstd_field(const int32_t* p) { return (int32_t)uni((uint32_t)*p); }
+
+template <class BP>
+CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
+{
+    ZstdWork* const w = reinterpret_cast<ZstdWork*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w_in)));
+    // (the tables: LDS on the device whenever this instance is the LDS one; the generic instance reads them as it finds them)
+    constexpr bool in_lds = !std::is_same<BP, const uint8_t*>::value;
+    using TP = typename std::conditional<in_lds, cimg_lds_cu32p, const uint32_t*>::type;
+    const TP tll = (TP)reinterpret_cast<const uint32_t*>(w->ll), tof = (TP)reinterpret_cast<const uint32_t*>(w->of), tml = (TP)reinterpret_cast<const uint32_t*>(w->ml);
+    const int ll_log = zstd_field(&w->ll_log), of_log = zstd_field(&w->of_log), ml_log = zstd_field(&w->ml_log);
+    const int nseq = zstd_field(&w->seq_nseq), bl = zstd_field(&w->seq_bl);
+    const int dcap = zstd_field(&w->seq_dcap), regen = zstd_field(&w->seq_regen);
+    int dpos = zstd_field(&w->seq_dpos), lpos = 0;
+    const uint8_t* const bs_g = reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->seq_bs)));
+    uint8_t* const dst = reinterpret_cast<uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->seq_dst)));
+    const uint8_t* const lit = reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->seq_lit)));
+    int r0 = zstd_field(&w->r0), r1 = zstd_field(&w->r1), r2 = zstd_field(&w->r2);
+    const BP bs = (BP)bs_g;
+    ZstdBits<BP> br;
+    br.init(bs, bl, bl * 8 - (8 - zstd_highbit(uni((uint32_t)bs[bl - 1]))));
+    const int llm = (1 << ll_log) - 1, ofm = (1 << of_log) - 1, mlm = (1 << ml_log) - 1;
+    int sl = (int)br.get(ll_log), so = (int)br.get(of_log), sm = (int)br.get(ml_log);
+    LV<int> vll, vml, vof;                                 // lane k: sequence k of the current batch of 64
+    FOR_LANES(l) { vll[l] = 0; vml[l] = 0; vof[l] = 1; }
+    // (the entries travel from one iteration to the next in VECTOR registers -- that is where a load lands -- and are made scalar at
+    // the top of the iteration that uses them: carried as scalars they would have to be waited for in the iteration that requests
+    // them; carried as vectors WITHOUT the uni() up here the compiler takes the whole loop for divergent control flow)
+    uint32_t pl_v = tll[sl & llm], po_v = tof[so & ofm], pm_v = tml[sm & mlm];
+    int err = 0;
+    // One sequence.  FAST: the reader stands at least 96 bits above the start of a stream of at least eight bytes -- more than a
+    // sequence can consume (31 + 16 + 16 extra bits, 26 bits of state) -- so no read needs a range check, and the symbols are not
+    // tested either (the tables are built from validated headers: nothing above the last code of its alphabet gets in).
+    auto step = [&](auto fast_tag, int i) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const uint32_t pl = uni(pl_v), po = uni(po_v), pm = uni(pm_v);
+        const int ls = (int)(pl & 0xFF), lnb = (int)((pl >> 8) & 0xFF), lbase = (int)(pl >> 16);
+        const int os = (int)(po & 0xFF), onb = (int)((po >> 8) & 0xFF), obase = (int)(po >> 16);
+        const int ms = (int)(pm & 0xFF), mnb = (int)((pm >> 8) & 0xFF), mbase = (int)(pm >> 16);
+        if (!FAST && (os > 31 || ls > 35 || ms > 52)) { err = ERR_DATA; return; }
+        // The extra bits of offset, match length and literal length lie one behind the other in the stream (first read = highest
+        // bits), and so do the three state updates: one read each when they fit 32 bits (they nearly always do) instead of three.
+        // (most sequences of an image have a literal length below 16 and a match length below 35: coded directly, no extra bits)
+        int xb = 0, xc = 0, mlen = ms + 3, llen = ls;
+        if (ms >= 32) { const uint32_t q = uni(zstd_ml_code_slow(ms)); xb = (int)(q & 0xFF); mlen = (int)(q >> 8); }
+        if (ls >= 16) { const uint32_t q = uni(zstd_ll_code_slow(ls)); xc = (int)(q & 0xFF); llen = (int)(q >> 8); }
+        const int xa = os & 31;
+        uint32_t xo;
+        if (xa + xb + xc <= 32) {
+            const uint32_t V = FAST ? br.getf(xa + xb + xc) : br.get(xa + xb + xc);
+            if (xb | xc) {
+                llen += (int)(V & ((1u << xc) - 1));
+                mlen += (int)((V >> xc) & ((1u << xb) - 1));
+                xo = xa ? V >> (xb + xc) : 0;
+            } else xo = V;
+        } else if (FAST) { xo = br.getf(xa); mlen += (int)br.getf(xb); llen += (int)br.getf(xc); }
+        else { xo = br.get(xa); mlen += (int)br.get(xb); llen += (int)br.get(xc); }
+        const uint32_t ov = (1u << xa) + xo;
+        if (i + 1 < nseq) {
+            const uint32_t V = FAST ? br.getf(lnb + mnb + onb) : br.get(lnb + mnb + onb);               // <= 9 + 9 + 8 bits
+            so = obase + (int)(V & ((1u << onb) - 1));
+            sm = mbase + (int)((V >> onb) & ((1u << mnb) - 1));
+            sl = lbase + (int)(V >> (onb + mnb));
+            // the next sequence's entries: requested now, used at the top of the next iteration
+            pl_v = tll[sl & llm]; po_v = tof[so & ofm]; pm_v = tml[sm & mlm];
+        }
+        if (!FAST && br.off < 0) { err = ERR_DATA; return; }
+        // (three named scalars, no indexing by idx: a dynamically indexed private array is scratch memory on the device)
+        int offset;
+        if (ov > 3) { offset = (int)(ov - 3); r2 = r1; r1 = r0; r0 = offset; }
+        else {
+            const int idx = (int)ov + (llen == 0 ? 1 : 0);
+            if (idx == 1) offset = r0;
+            else if (idx == 2) { offset = r1; r1 = r0; r0 = offset; }
+            else { offset = idx == 3 ? r2 : r0 - 1; r2 = r1; r1 = r0; r0 = offset; }
+        }
+        const int k = i & 63;
+        writelane(vll, k, llen); writelane(vml, k, mlen); writelane(vof, k, offset);
+    };
+    for (int i = 0; i < nseq; i++) {
+        if (bl >= 8 && br.off >= 96) step(std::true_type{}, i);
+        else step(std::false_type{}, i);
+        if (err) return err;
+        const int k = i & 63;
+        if (k == 63 || i + 1 == nseq) {
+            const int rc = zstd_execute_batch(dst, dcap, &dpos, lit, regen, &lpos, k + 1, vll, vml, vof, w);
+            if (rc < 0) return rc;
+        }
+    }
+    if (br.off != 0) return ERR_DATA;
+    FOR_LANES_W(l) { w->seq_lpos = lpos; w->r0 = r0; w->r1 = r1; w->r2 = r2; }
+    return dpos;
+}
+
 // ---- one compressed block ---------------------------------------------------------------------------------------------
 struct ZstdFrameState { int r0, r1, r2; };      // the three repeat offsets
 
@@ -433,8 +890,7 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
     const int stage_cap = w->tail ? w->stage_cap : 0;
     if (ltype == 0) {
         if (pos + regen > size) return ERR_DATA;
-        if (w->tail) zstd_stage(litbuf, src + pos, regen);
-        else lit = src + pos;                              // raw literals of a frame in LDS are used where they lie
+        zstd_stage(litbuf, src + pos, regen);              // (also from a frame in LDS: the batch executor reads its literals from the output area)
         pos += regen;
     } else if (ltype == 1) {
         if (pos + 1 > size) return ERR_DATA;
@@ -444,9 +900,15 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         if (pos + comp > size) return ERR_DATA;
         const uint8_t* ls = src + pos;
         int lsz = comp;
-        if (comp <= stage_cap) { zstd_stage(w->stage, ls, comp); ls = w->stage; }
+        bool ls_in_lds = !w->tail;                         // (a frame staged whole)
+        if (comp <= stage_cap) { zstd_stage(w->stage, ls, comp); ls = w->stage; ls_in_lds = true; }
         if (ltype == 2) {
+#ifdef CIMG_ABL_ZSTD_NO_TREE     /* timing experiment only: the table is not built (one with the same header length would be) */
+            const int t = lsz > 130 ? 64 : 1;
+            w->huf_log = 11;
+#else
             const int t = zstd_huf_read_tree(ls, lsz, w);
+#endif
             if (t < 0) return t;
             ls += t; lsz -= t;
         } else if (!w->have_huf) return ERR_DATA;
@@ -461,7 +923,24 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
             const int per = (regen + 3) / 4;
             if (3 * per > regen) return ERR_DATA;
             if (s1 < 1 || s2 < 1 || s3 < 1) return ERR_DATA;
-            const int rc = zstd_huf_stream4(ls + 6, s1, s2, s3, s4, litbuf, per, regen - 3 * per, w);
+            // (streams in the stage, or in a frame staged whole: LDS on the device -- the loop with typed pointers)
+            // (the table -- and the work area -- lie in LDS on the device: mem_lo says "this is the kernel"; the host tests take this
+            // path too, with plain pointers)
+            const bool ls_lds = ls_in_lds;
+            int rc = -1000;
+#ifdef CIMG_ABL_ZSTD_NO_HUF      /* timing experiment only: literals are not decoded */
+            rc = 0;
+#endif
+            // (streams in global memory: the windowed form measured 14.8 against 13.3 ms on the natural family -- CIMG_ZSTD_HUF_WINDOWS
+            // builds keep it for the next attempt; the lane loop below reads them where they lie)
+#ifdef CIMG_ZSTD_HUF_WINDOWS
+            const bool typed = w->mem_lo != nullptr;
+#else
+            const bool typed = w->mem_lo != nullptr && ls_lds;
+#endif
+            if (typed && rc == -1000)
+                rc = zstd_huf_stream4_lds(ls + 6, ls_lds, s1, s2, s3, s4, litbuf, per, regen - 3 * per, (cimg_lds_cu16p)CIMG_AS_LDS_CU16(w->huf), w->huf_log, w);
+            if (rc == -1000) rc = zstd_huf_stream4(ls + 6, s1, s2, s3, s4, litbuf, per, regen - 3 * per, w);
             if (rc < 0) return rc;
         }
         pos += comp;
@@ -506,63 +985,22 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         }
         const uint8_t* bs = src + pos;
         const int bl = size - pos;
-        if (bl >= 1 && bl <= stage_cap) { zstd_stage(w->stage, bs, bl); bs = w->stage; }
+        int bs_lds = w->tail ? 0 : 1;                      // (a frame staged whole lies in LDS)
+        if (bl >= 1 && bl <= stage_cap) { zstd_stage(w->stage, bs, bl); bs = w->stage; bs_lds = 1; }
         if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
-        ZstdBack br;
-        br.init(bs, bl, (int64_t)bl * 8 - (8 - zstd_highbit(zstd_u8(bs, bl - 1))));
-        const int llm = (1 << w->ll_log) - 1, ofm = (1 << w->of_log) - 1, mlm = (1 << w->ml_log) - 1;
-        int sl = (int)br.get(w->ll_log), so = (int)br.get(w->of_log), sm = (int)br.get(w->ml_log);
-        int r0 = fs->r0, r1 = fs->r1, r2 = fs->r2;
-        for (int i = 0; i < nseq; i++) {
-            // one 32-bit load per entry, and every lane loads the same three: say so, and the loop's control flow and addresses
-            // stay on the scalar unit
-            uint32_t pl, po, pm;
-            memcpy(&pl, &w->ll[sl & llm], 4); memcpy(&po, &w->of[so & ofm], 4); memcpy(&pm, &w->ml[sm & mlm], 4);
-            pl = uni(pl); po = uni(po); pm = uni(pm);
-            ZstdFseEntry el, eo, em;
-            el.sym = (uint8_t)pl; el.nb = (uint8_t)(pl >> 8); el.base = (uint16_t)(pl >> 16);
-            eo.sym = (uint8_t)po; eo.nb = (uint8_t)(po >> 8); eo.base = (uint16_t)(po >> 16);
-            em.sym = (uint8_t)pm; em.nb = (uint8_t)(pm >> 8); em.base = (uint16_t)(pm >> 16);
-            if (eo.sym > 31 || el.sym > 35 || em.sym > 52) return ERR_DATA;
-            // The extra bits of offset, match length and literal length lie one behind the other in the stream (first read =
-            // highest bits), and so do the three state updates: one read each when they fit 32 bits (they nearly always do)
-            // instead of three.
-            const int xa = eo.sym, xb = zstd_ml_bits(em.sym), xc = zstd_ll_bits(el.sym);
-            uint32_t xo, xm, xl;
-            if (xa + xb + xc <= 32) {
-                const uint32_t V = br.get(xa + xb + xc);
-                xl = V & ((1u << xc) - 1);
-                xm = (V >> xc) & ((1u << xb) - 1);
-                xo = xa ? V >> (xb + xc) : 0;
-            } else { xo = br.get(xa); xm = br.get(xb); xl = br.get(xc); }
-            const uint32_t ov = (1u << eo.sym) + xo;
-            const int mlen = zstd_ml_base(em.sym) + (int)xm;
-            const int llen = zstd_ll_base(el.sym) + (int)xl;
-            if (i + 1 < nseq) {
-                const uint32_t V = br.get(el.nb + em.nb + eo.nb);              // <= 9 + 9 + 8 bits
-                so = eo.base + (int)(V & ((1u << eo.nb) - 1));
-                sm = em.base + (int)((V >> eo.nb) & ((1u << em.nb) - 1));
-                sl = el.base + (int)(V >> (eo.nb + em.nb));
-            }
-            if (br.off < 0) return ERR_DATA;
-            // (three named scalars, no indexing by idx: a dynamically indexed private array is scratch memory on the device)
-            int offset;
-            if (ov > 3) { offset = (int)(ov - 3); r2 = r1; r1 = r0; r0 = offset; }
-            else {
-                const int idx = (int)ov + (llen == 0 ? 1 : 0);
-                if (idx == 1) offset = r0;
-                else if (idx == 2) { offset = r1; r1 = r0; r0 = offset; }
-                else { offset = idx == 3 ? r2 : r0 - 1; r2 = r1; r1 = r0; r0 = offset; }
-            }
-            if (llen > regen - lpos || llen > dcap - dpos) return ERR_DATA;
-            zstd_copy(dst + dpos, lit + lpos, llen);
-            dpos += llen; lpos += llen;
-            if (offset <= 0 || offset > dpos || mlen > dcap - dpos) return ERR_DATA;
-            zstd_match(dst + dpos, offset, mlen);
-            dpos += mlen;
+        FOR_LANES_W(l) {
+            w->seq_bs = bs; w->seq_bl = bl; w->seq_bs_lds = bs_lds; w->seq_nseq = nseq;
+            w->seq_dst = dst; w->seq_dcap = dcap; w->seq_dpos = dpos; w->seq_lit = lit; w->seq_regen = regen; w->seq_lpos = 0;
+            w->r0 = fs->r0; w->r1 = fs->r1; w->r2 = fs->r2;
         }
-        if (br.off != 0) return ERR_DATA;
-        fs->r0 = r0; fs->r1 = r1; fs->r2 = r2;
+#ifdef CIMG_ABL_ZSTD_NO_SEQ      /* timing experiment only */
+        if (nseq >= 0) return dpos;
+#endif
+        const int rc = (bs_lds && zstd_field((const int32_t*)&w->seq_bs_lds) && w->mem_lo != nullptr) ? zstd_sequences<cimg_lds_cu8p>(w) : zstd_sequences<const uint8_t*>(w);
+        if (rc < 0) return rc;
+        dpos = rc;
+        lpos = zstd_field(&w->seq_lpos);
+        fs->r0 = zstd_field(&w->r0); fs->r1 = zstd_field(&w->r1); fs->r2 = zstd_field(&w->r2);
     }
     const int rest = regen - lpos;
     if (rest > dcap - dpos) return ERR_DATA;

@@ -63,6 +63,8 @@ struct DecodeZstdBlock {
         uint8_t* const stage = lds + area + 16;
         w->stage = stage;
         w->stage_cap = ZSTD_KERNEL_STAGE;
+        w->mem_lo = lds;                                       // (the executor's 16-byte fetches may look anywhere in this workgroup's LDS)
+        w->mem_hi = lds + (a.lds_bytes & ~3);
         int pos = bstart;
         for (int s = 0; s < ns; s++) {
             if (cbytes - pos < 4) { fail(chunk, ERR_READ_BUFFER); return; }
@@ -86,7 +88,9 @@ struct DecodeZstdBlock {
                 if (staged) wave_copy_g2l(c + pos, lds, area + 16, cs);
                 w->tail = staged ? 0 : 1;
                 const int r = zstd_decode_frame(staged ? stage : c + pos, cs, plane, neblock, w);
+#if !defined(CIMG_ABL_ZSTD_NO_SEQ) && !defined(CIMG_ABL_ZSTD_NO_EXEC)
                 if (r != neblock) { fail(chunk, r < 0 ? r : ERR_DATA); return; }
+#endif
             }
             pos += payload;
         }
