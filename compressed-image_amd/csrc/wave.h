@@ -43,6 +43,8 @@ typedef volatile uint16_t* cimg_lds_vu16p;
 typedef const uint32_t* cimg_lds_cu32p;
 typedef const uint8_t* cimg_lds_cu8p;
 typedef const uint16_t* cimg_lds_cu16p;
+typedef uint8_t* cimg_lds_u8p;
+#define CIMG_AS_LDS_U8(p) ((uint8_t*)(p))
 #define CIMG_AS_LDS_CU16(p) ((const uint16_t*)(p))
 #define CIMG_AS_LDS_CU32(p) ((const uint32_t*)(p))
 #define CIMG_AS_LDS_CU8(p) ((const uint8_t*)(p))
@@ -175,6 +177,8 @@ typedef volatile __attribute__((address_space(3))) uint16_t* cimg_lds_vu16p;
 typedef const __attribute__((address_space(3))) uint32_t* cimg_lds_cu32p;
 typedef const __attribute__((address_space(3))) uint8_t* cimg_lds_cu8p;
 typedef const __attribute__((address_space(3))) uint16_t* cimg_lds_cu16p;
+typedef __attribute__((address_space(3))) uint8_t* cimg_lds_u8p;
+#define CIMG_AS_LDS_U8(p) ((cimg_lds_u8p)(p))
 #define CIMG_AS_LDS_CU16(p) ((cimg_lds_cu16p)(p))
 #define CIMG_AS_LDS_CU32(p) ((cimg_lds_cu32p)(p))
 #define CIMG_AS_LDS_CU8(p) ((cimg_lds_cu8p)(p))

@@ -590,10 +590,46 @@ CIMG_DEV void zstd_store_upto16(uint8_t* d, const u128& v, int n)
     for (int k = 0; k < 3; k++) { if (n > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
 }
 
-CIMG_DEV void zstd_copy(uint8_t* dst, const uint8_t* src, int n);
-CIMG_DEV void zstd_match(uint8_t* dst, int offset, int n);
+// the byte movers on a typed pointer (DP = cimg_lds_u8p in the kernel: ds_* instructions instead of flat ones)
+template <class DP> CIMG_DEV u128 zstd_fetch16_t(DP p)
+{
+    const uint32_t sh = (uint32_t)((uintptr_t)p & 3u);
+    using WP = typename std::conditional<std::is_same<DP, uint8_t*>::value, const uint32_t*, cimg_lds_cu32p>::type;
+    const WP q = (WP)(p - sh);
+    const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    u128 r;
+    r.x = alignbyte(q1, q0, sh); r.y = alignbyte(q2, q1, sh); r.z = alignbyte(q3, q2, sh); r.w = alignbyte(q4, q3, sh);
+    return r;
+}
+template <class DP> CIMG_DEV void zstd_store_upto16_t(DP d, const u128& v, int n)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    CIMG_UNROLL
+    for (int j = 0; j < 4; j++) { if (n >= 4 * j + 4) __builtin_memcpy(d + 4 * j, &w[j], 4); }
+    const int t = n > 0 ? (n > 16 ? 16 : n) & ~3 : 0;
+    const uint32_t last = t < 16 ? w[(t >> 2) & 3] : 0;
+    CIMG_UNROLL
+    for (int k = 0; k < 3; k++) { if (n > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+}
+template <class DP> CIMG_DEV void zstd_copy_t(DP dst, DP src, int n)
+{
+    for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = src[k0 + l]; } }
+}
+template <class DP> CIMG_DEV void zstd_match_t(DP dst, int offset, int n)
+{
+    if (offset >= 64 || offset >= n) {
+        for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = dst[k0 + l - offset]; } }
+        return;
+    }
+    const DP pat = dst - offset;
+    for (int k0 = 0; k0 < n; k0 += 64) { FOR_LANES_W(l) { if (k0 + l < n) dst[k0 + l] = pat[(k0 + l) % offset]; } }
+}
 
-CIMG_DEV int zstd_execute_batch(uint8_t* dst, int dcap, int* dpos_io, const uint8_t* lit, int regen, int* lpos_io, int nb,
+#ifdef CIMG_EMULATE
+extern long g_emu_zx_batches, g_emu_zx_rounds, g_emu_zx_par, g_emu_zx_serial, g_emu_zx_longlit;   // test-side statistics only
+#endif
+template <class DP>
+CIMG_DEV int zstd_execute_batch(DP dst, int dcap, int* dpos_io, DP lit, int regen, int* lpos_io, int nb,
                                 const LV<int>& vll, const LV<int>& vml, const LV<int>& vof, const ZstdWork* w)
 {
     const int dpos = *dpos_io, lpos = *lpos_io;
@@ -630,11 +666,11 @@ CIMG_DEV int zstd_execute_batch(uint8_t* dst, int dcap, int* dpos_io, const uint
         LV<u128> first;
         LV<bool> fast, slow;
         FOR_LANES(l) {
-            const uint8_t* sp = lit + lpos + lsum[l];
-            const uintptr_t a = (uintptr_t)sp & ~(uintptr_t)3;
+            const DP sp = lit + lpos + lsum[l];
+            const uintptr_t a = (uintptr_t)(const uint8_t*)(sp) & ~(uintptr_t)3;
             fast[l] = act[l] & (ll[l] > 0) & (mlo != nullptr) & (a >= (uintptr_t)mlo) & (a + 20 <= (uintptr_t)mhi);
             slow[l] = act[l] & (ll[l] > 0) & !fast[l];
-            if (mlo != nullptr) first[l] = zstd_fetch16(fast[l] ? sp : mlo);          // (a lane that is not fast fetches from mem_lo and drops it)
+            if (mlo != nullptr) first[l] = zstd_fetch16_t<DP>(fast[l] ? sp : dst);          // (a lane that is not fast fetches from the start of the output and drops it)
             else { first[l].x = 0; first[l].y = 0; first[l].z = 0; first[l].w = 0; }
         }
         // runs with more than 16 bytes (and runs next to unreadable memory: whole) in sequence order, by the whole wave
@@ -642,14 +678,17 @@ CIMG_DEV int zstd_execute_batch(uint8_t* dst, int dcap, int* dpos_io, const uint
         FOR_LANES(l) { longer[l] = slow[l] | (fast[l] & (ll[l] > 16)); }
         uint64_t todo = ballot(longer);
         const uint64_t whole = ballot(slow);
+#ifdef CIMG_EMULATE
+        g_emu_zx_batches++; g_emu_zx_longlit += popc64(todo);
+#endif
         while (todo) {
             const int t = ctz64(todo);
             todo &= todo - 1;
             const int n = readlane(ll, t), d = readlane(D, t), sp = lpos + readlane(lsum, t);
             const int skip = ((whole >> t) & 1) ? 0 : 16;
-            zstd_copy(dst + d + skip, lit + sp + skip, n - skip);
+            zstd_copy_t<DP>(dst + d + skip, lit + sp + skip, n - skip);
         }
-        FOR_LANES_W(l) { if (fast[l]) zstd_store_upto16(dst + D[l], first[l], ll[l] < 16 ? ll[l] : 16); }
+        FOR_LANES_W(l) { if (fast[l]) zstd_store_upto16_t<DP>(dst + D[l], first[l], ll[l] < 16 ? ll[l] : 16); }
     }
     // ---- matches
     uint64_t pending;
@@ -665,25 +704,28 @@ CIMG_DEV int zstd_execute_batch(uint8_t* dst, int dcap, int* dpos_io, const uint
         FOR_LANES(l) {
             const int S = M[l] - of[l];
             const bool fill = of[l] == 1;
-            const uintptr_t a = (uintptr_t)(dst + S) & ~(uintptr_t)3;
+            const uintptr_t a = (uintptr_t)(const uint8_t*)(dst + S) & ~(uintptr_t)3;
             const bool readable = (mlo != nullptr) & (a >= (uintptr_t)mlo) & (a + 20 <= (uintptr_t)mhi);
             const bool apart = (of[l] >= ml[l]) | fill;                                    // does not read what it writes (a fill reads one byte)
             const bool done_src = (S + (fill ? 1 : ml[l]) <= F) | ((S >= D[l]) & (of[l] >= ml[l]));   // finished output, or its own literals
             ready[l] = ((pending >> l) & 1) & (ml[l] <= 16) & apart & done_src & readable;
         }
         const uint64_t rmask = ballot(ready);
+#ifdef CIMG_EMULATE
+        g_emu_zx_rounds++; if (rmask) g_emu_zx_par += popc64(rmask); else g_emu_zx_serial++;
+#endif
         if (rmask) {
             LV<u128> v;
             FOR_LANES(l) {
                 const int S = M[l] - of[l];
-                v[l] = zstd_fetch16(ready[l] ? dst + S : mlo);                              // (rmask != 0: there is a readable range)
+                v[l] = zstd_fetch16_t<DP>(ready[l] ? dst + S : dst);                              // (rmask != 0: there is a readable range)
                 if (of[l] == 1) { const uint32_t f = (v[l].x & 0xFF) * 0x01010101u; v[l].x = f; v[l].y = f; v[l].z = f; v[l].w = f; }
             }
-            FOR_LANES_W(l) { if (ready[l]) zstd_store_upto16(dst + M[l], v[l], ml[l]); }
+            FOR_LANES_W(l) { if (ready[l]) zstd_store_upto16_t<DP>(dst + M[l], v[l], ml[l]); }
             pending &= ~rmask;
         } else {
             // the first pending match: all output in front of it is final
-            zstd_match(dst + F, readlane(of, t0), readlane(ml, t0));
+            zstd_match_t<DP>(dst + F, readlane(of, t0), readlane(ml, t0));
             pending &= pending - 1;
         }
     }
@@ -845,7 +887,9 @@ CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
         if (err) return err;
         const int k = i & 63;
         if (k == 63 || i + 1 == nseq) {
-            const int rc = zstd_execute_batch(dst, dcap, &dpos, lit, regen, &lpos, k + 1, vll, vml, vof, w);
+            // (the output area -- and the literals at its end -- lie in LDS whenever this is the LDS instance)
+            using DP = typename std::conditional<in_lds, cimg_lds_u8p, uint8_t*>::type;
+            const int rc = zstd_execute_batch<DP>((DP)dst, dcap, &dpos, (DP)const_cast<uint8_t*>(lit), regen, &lpos, k + 1, vll, vml, vof, w);
             if (rc < 0) return rc;
         }
     }
