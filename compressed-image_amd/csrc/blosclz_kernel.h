@@ -356,29 +356,203 @@ CIMG_DEV int blosclz_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t
 // output goes to [base, base + n).  Returns 0 or ERR_DATA (c-blosc2 treats any result != n as an error).  Every LDS
 // index is clamped to lds_limit, so a damaged stream gives garbage + an error, never an out-of-range access.
 // Checks follow the library one to one (oracle/blosclz.c), including "a far match that ends the input is not copied".
+// Round 4: tokens are taken a 64-byte window at a time, as the LZ4 decoder takes its sequences (decode_kernel.h, "batch path").
+// Until then every token was a round trip of its own -- a thousand cycles each, and a byte plane of an image is a hundred to a
+// thousand tokens (a control byte below 32: a run of up to 32 literals; from 32 on: a match -- three bits of length, possibly
+// length bytes, an offset byte, possibly two more for a far offset).  Every lane assumes a token starts at its byte and parses
+// it from five bytes (ONE round trip: all five addresses are known up front); a scalar walk follows the real chain; a prefix sum
+// places the tokens' output; the literal runs of the whole window go out in one store (they ARE the window's bytes); matches that
+// read nothing this window writes are copied sixteen at a time, four lanes each, the rest in order.  What a window cannot take
+// -- the first token of a stream (its control byte is a literal count whatever its top bits say), a length that needs more
+// than one length byte, a literal run that leaves the window, the last tokens of the stream -- goes through the token-by-token
+// loop below, which is the round-2 decoder.  Same checks, same results on damaged streams (tests/emu runs both forms).
 CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, int lds_limit)
 {
     if (csize <= 0) return ERR_DATA;
     const int iend = cs + csize, oend = base + n;
     const int clampmax = lds_limit - 1;
-    int ip = cs, op = base;
-    // lane l holds input byte wbase + l.  A literal run (<= 32 bytes + the next control byte) or a match header (<= 4
-    // bytes + the next control byte) that starts in the first 28 bytes of the window is served from these registers, so
-    // most windows feed several tokens: the window is only re-read when the current token starts behind byte 27.
-    LV<uint32_t> w;
-    int wbase = ip;
-    FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
-    uint32_t ctrl = readlane(w, 0) & 31u;
-    ip++;
-    // ONE way out of the token loop (`break`, with `bad` set for a damaged stream): returns inside it make the compiler dispatch
-    // every iteration on an exit selector, and an iteration here is one token (encode_kernel.h has the measurement)
-    bool bad = false;
+    int ip = cs, op = base;                                // ip: at the control byte of the next token
+    LV<uint32_t> w;                                        // token-by-token loop: lane l holds input byte wbase + l
+    int wbase = -4096;
+    bool first = true, bad = false;
     for (int guard = 0; guard <= csize + 1; ++guard) {
+        if (ip >= iend) break;
+#ifndef CIMG_BLZ_NO_BATCH
+        if (!first && iend - ip >= 8) {
+            // ---- batch: every token of the next 64 input bytes that the window can take ------------------------------------------
+            LV<uint32_t> c0;
+            LV<int> lit_l, walk_l, len_l, off_l, ml_l;
+            LV<bool> good;
+            enum : int { WALK_BAD = 0x2000 };
+            FOR_LANES(l) {
+                const int at = ip + l;
+                c0[l] = lds[imin(at, clampmax)];
+                const uint32_t b1 = lds[imin(at + 1, clampmax)], b2 = lds[imin(at + 2, clampmax)];
+                const uint32_t b3 = lds[imin(at + 3, clampmax)], b4 = lds[imin(at + 4, clampmax)];
+                const uint32_t c = c0[l];
+                const bool is_lit = c < 32;
+                const int lf = (int)(c >> 5);
+                const bool ext = lf == 7;
+                const uint32_t code = ext ? b2 : b1;
+                const bool far = (code == 255) & ((c & 31u) == 31u);
+                const uint32_t f1 = ext ? b3 : b2, f2 = ext ? b4 : b3;
+                const int dist = far ? BLZ_MAX_DISTANCE + (int)((f1 << 8) + f2) + 1 : (int)((c & 31u) << 8) + (int)code + 1;
+                const int hdr = 2 + (ext ? 1 : 0) + (far ? 2 : 0);
+                lit_l[l] = is_lit ? (int)c + 1 : 0;
+                ml_l[l] = is_lit ? 0 : lf + 2 + (ext ? (int)b1 : 0);
+                off_l[l] = is_lit ? 0 : dist;
+                const int nxt = l + (is_lit ? 1 + lit_l[l] : hdr);
+                len_l[l] = lit_l[l] + ml_l[l];
+                // (one length byte only; a following token exists: the last tokens of a stream go the slow way, with its checks)
+                good[l] = (is_lit | !ext | (b1 < 255)) & (ip + nxt < iend);
+                // a literal run that leaves the window is copied LDS -> LDS, for the LAST token of a batch only (flag + 1024)
+                walk_l[l] = good[l] ? nxt + ((is_lit & (nxt > 64)) ? 1024 : 0) : (int)WALK_BAD;
+            }
+            uint64_t tokens = 0;
+            int s = 0, t_ = 0;
+#define CIMG_WALK_STEP t_ = readlane(walk_l, s); if (t_ > 63) break; tokens |= 1ull << s; s = t_;
+            for (int rnd = 0; rnd < 4; ++rnd) {
+                CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP
+            }
+#undef CIMG_WALK_STEP
+            if (t_ > 63 && !(t_ & WALK_BAD)) { tokens |= 1ull << s; s = t_; }
+            int biglast = 0;
+            if (s >= 1024) { s -= 1024; biglast = 1; }
+            LV<int> tlen, opos;
+            LV<bool> istok;
+            FOR_LANES(l) { istok[l] = (tokens >> l) & 1; tlen[l] = istok[l] ? len_l[l] : 0; }
+            int acc;
+            wave_exscan(tlen, opos, acc);
+            if (acc > oend - op) {                                 // cut the batch at the first token that does not fit
+                const int room = oend - op;
+                LV<bool> over;
+                FOR_LANES(l) { over[l] = istok[l] & (opos[l] + tlen[l] > room); }
+                const int f = ctz64(ballot(over));
+                tokens &= (1ull << f) - 1;
+                s = f;
+                biglast = 0;
+                acc = readlane(opos, f);
+                FOR_LANES(l) { istok[l] = (tokens >> l) & 1; }
+            }
+            if (tokens) {
+                // literals: lane j belongs to the last token at or before j - 1 (a run's bytes follow its control byte)
+                const int tlast = 63 - (int)__builtin_clzll(tokens);
+                const int litlim = biglast ? tlast : imin(s, 64);
+                LV<int> owner;
+                LV<bool> is_lit;
+                FOR_LANES(l) {
+                    const uint64_t below = tokens & ((1ull << l) - 1);
+                    owner[l] = below ? 63 - (int)__builtin_clzll(below) : 0;
+                    is_lit[l] = below != 0;
+                }
+                LV<int> own_lit, own_pos;
+                lane_gather(lit_l, owner, own_lit);
+                lane_gather(opos, owner, own_pos);
+                FOR_LANES_W(l) {
+                    const int k = l - owner[l] - 1;
+                    if (is_lit[l] & (k < own_lit[l]) & (l < litlim)) lds[op + own_pos[l] + k] = (uint8_t)c0[l];
+                }
+                if (biglast) lds_copy_bytes(lds, op + readlane(opos, tlast), ip + tlast + 1, readlane(lit_l, tlast));
+                // matches
+                LV<int> dstv, srcv;
+                LV<bool> badv, hasm;
+                FOR_LANES(l) {
+                    dstv[l] = op + opos[l];                        // (a match token has no literals of its own)
+                    srcv[l] = dstv[l] - off_l[l];
+                    hasm[l] = istok[l] & (ml_l[l] > 0);
+                    badv[l] = hasm[l] & (srcv[l] < base);
+                }
+                if (ballot(badv)) return ERR_DATA;
+                LV<bool> par;
+                FOR_LANES(l) {
+                    const int off = off_l[l], ml = ml_l[l];
+                    par[l] = hasm[l] & (ml <= 64) & ((off >= ml) | (off == 1)) & (srcv[l] + (off == 1 ? 1 : ml) <= op);
+                }
+                uint64_t parmask = ballot(par);
+                if (popc64(parmask) < 3) parmask = 0;
+                if (parmask) {
+                    const int P = popc64(parmask);
+                    LV<int> rank, d0, d1, D0, D1;
+                    FOR_LANES(l) {
+                        rank[l] = par[l] ? lane_rank(parmask, l) : 63;
+                        d0[l] = dstv[l] | (ml_l[l] << 18);
+                        d1[l] = srcv[l] | (off_l[l] == 1 ? 1 << 18 : 0);
+                    }
+                    lane_scatter(d0, rank, D0);
+                    lane_scatter(d1, rank, D1);
+                    for (int g = 0; g < P; g += 16) {
+                        LV<int> who, e0, e1;
+                        FOR_LANES(l) { who[l] = g + (l >> 2); }
+                        lane_gather(D0, who, e0);
+                        lane_gather(D1, who, e1);
+                        LV<u128> wv;
+                        FOR_LANES(l) {
+                            const bool act = who[l] < P;
+                            const bool f = (e1[l] >> 18) & 1;
+                            const int sa = act ? (e1[l] & 0x3FFFF) + (f ? 0 : (l & 3) * 16) : base;
+                            const int a = sa & ~3;
+                            const uint32_t sh = (uint32_t)sa & 3u;
+                            const uint32_t q0 = *reinterpret_cast<const uint32_t*>(lds + a);
+                            const uint32_t q1 = *reinterpret_cast<const uint32_t*>(lds + a + 4);
+                            const uint32_t q2 = *reinterpret_cast<const uint32_t*>(lds + a + 8);
+                            const uint32_t q3 = *reinterpret_cast<const uint32_t*>(lds + a + 12);
+                            const uint32_t q4 = *reinterpret_cast<const uint32_t*>(lds + a + 16);
+                            const uint32_t x0 = alignbyte(q1, q0, sh);
+                            const uint32_t fb = (x0 & 0xFF) * 0x01010101u;
+                            wv[l].x = f ? fb : x0;
+                            wv[l].y = f ? fb : alignbyte(q2, q1, sh);
+                            wv[l].z = f ? fb : alignbyte(q3, q2, sh);
+                            wv[l].w = f ? fb : alignbyte(q4, q3, sh);
+                        }
+                        FOR_LANES_W(l) {
+                            const int rem = who[l] < P ? ((e0[l] >> 18) & 0x7F) - (l & 3) * 16 : 0;
+                            uint8_t* d = lds + (e0[l] & 0x3FFFF) + (l & 3) * 16;
+                            const uint32_t v[4] = {wv[l].x, wv[l].y, wv[l].z, wv[l].w};
+                            CIMG_UNROLL
+                            for (int j = 0; j < 4; j++) { if (rem >= 4 * j + 4) lds_st32u(d + 4 * j, v[j]); }
+                            const int t = rem > 0 ? (rem > 16 ? 16 : rem) & ~3 : 0;
+                            const uint32_t last = t < 16 ? v[(t >> 2) & 3] : 0;
+                            CIMG_UNROLL
+                            for (int k = 0; k < 3; k++) { if (rem > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+                        }
+                    }
+                }
+                uint64_t todo = ballot(hasm) & ~parmask;
+                while (todo) {
+                    const int t = ctz64(todo);
+                    todo &= todo - 1;
+                    const int dst = readlane(dstv, t), src = readlane(srcv, t), ml = readlane(ml_l, t);
+                    const int offset = dst - src;
+                    if (ml <= 64) {
+                        LV<uint32_t> mv;
+                        if (offset >= ml) { FOR_LANES(l) { mv[l] = lds[src + (l < ml ? l : 0)]; } }
+                        else if (offset == 1) { FOR_LANES(l) { mv[l] = lds[src]; } }
+                        else {
+                            const float inv = fast_rcp((float)offset);
+                            FOR_LANES(l) { mv[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
+                        }
+                        FOR_LANES_W(l) { if (l < ml) lds[dst + l] = (uint8_t)mv[l]; }
+                    } else {
+                        lds_copy_match(lds, dst, src, ml);
+                    }
+                }
+                ip += s;
+                op += acc;
+                wbase = -4096;                                     // (the token-by-token window is stale)
+                continue;
+            }
+        }
+#endif
+        // ---- one token the slow way (the round-2 decoder): lane l holds input byte wbase + l; a literal run (<= 32 bytes) or a match
+        // header (<= 5 bytes) that starts in the first 28 bytes of the window is served from these registers
         int k = ip - wbase;
-        if (k > 27) {
+        if (k > 27 || k < 0) {
             wbase = ip; k = 0;
             FOR_LANES(l) { w[l] = lds[imin(wbase + l, clampmax)]; }
         }
+        uint32_t ctrl = readlane(w, k);
+        if (first) { ctrl &= 31u; first = false; }
+        k++;                                                   // k: the byte behind the control byte
         if (ctrl >= 32) {
             int len = (int)(ctrl >> 5) - 1;
             int ofs = (int)(ctrl & 31u) << 8;
@@ -414,9 +588,6 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
             }
             if (len > oend - op || ref - 1 < base) { bad = true; break; }
             ip = wbase + k;
-            if (ip >= iend) break;
-            ctrl = readlane(w, k);
-            ip++;
             ref--;
             if (len <= 64) {
                 const int offset = op - ref;
@@ -435,13 +606,11 @@ CIMG_DEV int blosclz_decode_wave(uint8_t* lds, int base, int n, int cs, int csiz
             }
             op += len;
         } else {
-            const int cnt = (int)ctrl + 1;                   // <= 32: the run and the next control byte are in the window
+            const int cnt = (int)ctrl + 1;                   // <= 32: the run is in the window
+            ip = wbase + k;
             if (cnt > oend - op || ip + cnt > iend) { bad = true; break; }
             FOR_LANES_W(l) { if (l >= k && l < k + cnt) lds[op + l - k] = (uint8_t)w[l]; }
             op += cnt; ip += cnt;
-            if (ip >= iend) break;
-            ctrl = readlane(w, k + cnt);
-            ip++;
         }
     }
     return (!bad && op == oend) ? 0 : ERR_DATA;
