@@ -817,6 +817,7 @@ def main():
     else:
         total_c = float(cbytes.sum())
 
+    cbytes = np.array(cbytes, copy=True)            # (the marshalled step hands back ONE array, rewritten by every later call: keep this batch's sizes)
     ktimes = [eng.kernel_time(k) for k in range(4)]
     ksamples = [eng.kernel_samples(k) for k in range(4)]
     dstats = eng.decode_stats()
