@@ -27,7 +27,7 @@ EXPORTS = (
     "cimg_cparams_init", "cimg_engine_create", "cimg_engine_destroy", "cimg_last_error",
     "cimg_engine_synchronize", "cimg_engine_lock", "cimg_engine_unlock", "cimg_engine_stream", "cimg_compress_batch_device",
     "cimg_decompress_batch_device", "cimg_compress_batch_host", "cimg_decompress_batch_host", "cimg_decompress_batch_host_sized",
-    "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch",
+    "cimg_compress_batch_host_begin", "cimg_compress_batch_host_fetch", "cimg_compress_batch_host_packed",
     "cimg_deinterleave_device", "cimg_compress_batch_host_interleaved_begin",
     "cimg_compress_batch_device_begin", "cimg_compress_batch_device_fetch", "cimg_decompress_batch_device_begin", "cimg_decompress_batch_device_fetch",
     "cimg_decompress_batch_device_sized", "cimg_decompress_batch_device_begin_sized",

@@ -1085,33 +1085,46 @@ struct Groups {
 // everything when the registration fails (the copies then run as before).  Nothing stays registered behind the call: the
 // engine cannot know when the caller frees the buffer.
 struct HostPin {
-    void* base = nullptr;
+    enum : int { MAX_RUNS = 32 };
+    void* base[MAX_RUNS];
+    int nruns = 0;
     cimg_engine* eng;
+    // The chunks of a batch may lie in several separate allocations (an image handed over as one array per channel): they are
+    // grouped into runs of memory (gaps of up to 64 KiB bridged) and every run of at least 4 MiB is registered by itself.
     HostPin(cimg_engine* e, const void* host, const int64_t* off, const int32_t* len, int n, bool writable) : eng(e)
     {
         (void)writable;
         if (!host || n <= 0 || e->host_register_bytes <= 0) return;
-        int64_t lo = INT64_MAX, hi = INT64_MIN, total = 0;
-        for (int i = 0; i < n; i++) {
-            if (len[i] <= 0) continue;
-            lo = std::min(lo, off[i]); hi = std::max(hi, off[i] + (int64_t)len[i]); total += len[i];
+        int64_t total = 0;
+        std::vector<std::pair<int64_t, int64_t>> seg;
+        seg.reserve((size_t)n);
+        for (int i = 0; i < n; i++) if (len[i] > 0) { seg.emplace_back(off[i], off[i] + (int64_t)len[i]); total += len[i]; }
+        if (total < e->host_register_bytes || seg.empty()) return;
+        std::sort(seg.begin(), seg.end());
+        std::vector<std::pair<int64_t, int64_t>> runs;
+        for (const auto& sg : seg) {
+            if (!runs.empty() && sg.first <= runs.back().second + 65536) runs.back().second = std::max(runs.back().second, sg.second);
+            else runs.push_back(sg);
         }
-        if (total < e->host_register_bytes || hi <= lo || (hi - lo) > 2 * total) return;       // (a sparse span would pin what is never copied)
-        const uintptr_t a = ((uintptr_t)host + (uintptr_t)lo) & ~(uintptr_t)4095;
-        const uintptr_t b = (((uintptr_t)host + (uintptr_t)hi) + 4095) & ~(uintptr_t)4095;
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, (const void*)a) == hipSuccess && at.type != hipMemoryTypeUnregistered) return;   // page-locked already
-        (void)hipGetLastError();
-        if (hipHostRegister((void*)a, (size_t)(b - a), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return; }
-        base = (void*)a;
-        e->host_registrations++;
+        for (const auto& r : runs) {
+            if (nruns >= MAX_RUNS) break;
+            if (r.second - r.first < (4ll << 20)) continue;
+            const uintptr_t a = ((uintptr_t)host + (uintptr_t)r.first) & ~(uintptr_t)4095;
+            const uintptr_t b = (((uintptr_t)host + (uintptr_t)r.second) + 4095) & ~(uintptr_t)4095;
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, (const void*)a) == hipSuccess && at.type != hipMemoryTypeUnregistered) continue;   // page-locked already
+            (void)hipGetLastError();
+            if (hipHostRegister((void*)a, (size_t)(b - a), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); continue; }
+            base[nruns++] = (void*)a;
+            e->host_registrations++;
+        }
     }
     ~HostPin()
     {
-        if (!base) return;
+        if (!nruns) return;
         // (every regular return has waited for its copies; an error return in the middle of a pipeline may not have)
         (void)hipStreamSynchronize(eng->s_h2d); (void)hipStreamSynchronize(eng->s_d2h); (void)hipStreamSynchronize(eng->stream);
-        (void)hipHostUnregister(base);
+        for (int i = 0; i < nruns; i++) (void)hipHostUnregister(base[i]);
     }
     HostPin(const HostPin&) = delete;
     HostPin& operator=(const HostPin&) = delete;
@@ -1152,9 +1165,34 @@ int copy_out(cimg_engine* e, hipStream_t st, uint8_t* host, const int64_t* host_
     return 0;
 }
 
+// chunks [a, b) of a finished group -> a block of host memory the caller hands out now that their sizes are known
+int packed_out(cimg_engine* e, hipStream_t st, cimg_alloc_fn alloc, void* user, void** chunk_ptr, const uint8_t* dev, const int64_t* dev_off,
+               const int32_t* cbytes, int a, int b)
+{
+    size_t total = 0;
+    for (int i = a; i < b; i++) {
+        if (cbytes[i] < 0) return e->fail(cbytes[i], "chunk %d failed to compress (code %d)", i, cbytes[i]);
+        total += ((size_t)cbytes[i] + 63) & ~(size_t)63;
+    }
+    if (!total) { for (int i = a; i < b; i++) chunk_ptr[i] = nullptr; return 0; }
+    uint8_t* block = (uint8_t*)alloc(user, total);
+    if (!block) return e->fail(ERR_FAILURE, "the caller's allocator returned no memory for %zu bytes of chunks", total);
+    std::vector<int64_t> hoff((size_t)b, 0);             // (indexed by chunk, like every offset table of copy_out)
+    size_t at = 0;
+    for (int i = a; i < b; i++) {
+        hoff[(size_t)i] = (int64_t)at;
+        chunk_ptr[i] = cbytes[i] > 0 ? block + at : nullptr;
+        at += ((size_t)cbytes[i] + 63) & ~(size_t)63;
+    }
+    return copy_out(e, st, block, hoff.data(), dev, dev_off, cbytes, a, b, "chunk D2H");
+}
+
 // compress from host pixels; chunks stay in the device staging area, and go to h_comp as well when it is given
+// (alloc != nullptr: the chunks of every group go, packed back to back at 64-byte boundaries, into a block the caller hands out when
+// the group's sizes are known -- cimg_compress_batch_host_packed -- and chunk_ptr[i] says where chunk i went)
 int compress_host_pipeline(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw, const int64_t* raw_off,
-                           const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes, void* h_comp, const int64_t* comp_off)
+                           const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes, void* h_comp, const int64_t* comp_off,
+                           cimg_alloc_fn alloc = nullptr, void* alloc_user = nullptr, void** chunk_ptr = nullptr)
 {
     e->fetch_off.clear();
     if (!p || !h_raw || !raw_off || !nbytes || !destsize || !cbytes) return e->fail(ERR_INVALID_PARAM, "null argument");
@@ -1192,6 +1230,9 @@ int compress_host_pipeline(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         if (h_comp) {
             if ((rc = copy_out(e, e->stream, (uint8_t*)h_comp, comp_off, sc, d_comp_off.data(), cbytes, 0, nchunks, "chunk D2H"))) return rc;
             if ((rc = cimg_engine_synchronize(e))) return rc;
+        } else if (alloc) {
+            if ((rc = packed_out(e, e->stream, alloc, alloc_user, chunk_ptr, sc, d_comp_off.data(), cbytes, 0, nchunks))) return rc;
+            if ((rc = cimg_engine_synchronize(e))) return rc;
         }
         e->fetch_off = std::move(d_comp_off);
         e->fetch_len.assign(cbytes, cbytes + nchunks);
@@ -1211,8 +1252,10 @@ int compress_host_pipeline(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
         if (rc || frc) { (void)hipStreamSynchronize(e->s_h2d); (void)hipStreamSynchronize(e->s_d2h); return rc ? rc : frc; }
         if (h_comp)
             if ((rc = copy_out(e, e->s_d2h, (uint8_t*)h_comp, comp_off, sc, d_comp_off.data(), cbytes, a, b, "chunk D2H"))) { (void)hipStreamSynchronize(e->s_d2h); return rc; }
+        if (!h_comp && alloc)
+            if ((rc = packed_out(e, e->s_d2h, alloc, alloc_user, chunk_ptr, sc, d_comp_off.data(), cbytes, a, b))) { (void)hipStreamSynchronize(e->s_d2h); return rc; }
     }
-    if (h_comp) { if ((rc = e->hip(hipStreamSynchronize(e->s_d2h), "chunk D2H"))) return rc; }
+    if (h_comp || alloc) { if ((rc = e->hip(hipStreamSynchronize(e->s_d2h), "chunk D2H"))) return rc; }
     e->fetch_off = std::move(d_comp_off);
     e->fetch_len.assign(cbytes, cbytes + nchunks);
     return 0;
@@ -1303,6 +1346,17 @@ int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp
     e->fetch_off.clear();
     const int src = e->hip(hipStreamSynchronize(e->s_d2h), "chunk D2H");
     return rc ? rc : src;
+}
+
+int cimg_compress_batch_host_packed(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw, const int64_t* raw_off,
+                                    const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes, cimg_alloc_fn alloc, void* user, void** chunk_ptr)
+{
+    std::lock_guard<std::recursive_mutex> lock_(e->mu);
+    if (nchunks <= 0) return 0;
+    if (!alloc || !chunk_ptr) return e->fail(ERR_INVALID_PARAM, "null argument");
+    const int rc = compress_host_pipeline(e, p, nchunks, h_raw, raw_off, nbytes, destsize, cbytes, nullptr, nullptr, alloc, user, chunk_ptr);
+    e->fetch_off.clear();                                  // delivered: nothing is left to fetch
+    return rc;
 }
 
 int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw,

@@ -239,26 +239,42 @@ namespace NAMESPACE_COMPRESSED_IMAGE
 					explicit engine_guard(cimg_engine* e_) : e(e_) { cimg_engine_lock(e); }
 					~engine_guard() { cimg_engine_unlock(e); }
 				} pair_lock(engine());
-				// step 1: upload + compress; the chunks stay on the device and their sizes come back
-				rc = cimg_compress_batch_host_begin(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(), destsize.data(), cbytes.data());
+				// ONE call: upload, compress and bring the chunks back group by group -- as soon as the sizes of a group are known the
+				// engine asks for a block of exactly that size (recycled, page-locked: detail/pinned_pool.h) and sends the group's
+				// chunks there while the next group is being compressed; the chunks are views into those blocks -- no staging area of
+				// nominal size, no second copy.  (Round 3 fetched all chunks behind the last group: 4.2 against 3.0 ms for an image of
+				// 4 x 4096^2 float16.)
+				struct arenas_t
+				{
+					std::vector<std::pair<std::shared_ptr<std::byte>, size_t>> blocks;
+					static void* take(void* user, size_t bytes)
+					{
+						auto* self = static_cast<arenas_t*>(user);
+						try
+						{
+							self->blocks.emplace_back(NAMESPACE_COMPRESSED_IMAGE::detail::pinned_pool::get().arena(bytes), bytes);
+						}
+						catch (...) { return nullptr; }
+						return self->blocks.back().first.get();
+					}
+				} arenas;
+				std::vector<void*> where(n, nullptr);
+				rc = cimg_compress_batch_host_packed(engine(), &cp, static_cast<int32_t>(n), base, raw_off.data(), nbytes.data(), destsize.data(), cbytes.data(),
+					&arenas_t::take, &arenas, where.data());
 				if (rc < 0)
 					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
-				size_t total = 0;
 				for (size_t i = 0; i < n; ++i)
 				{
-					if (cbytes[i] <= 0)
+					if (cbytes[i] <= 0 || !where[i])
 						throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", cbytes[i]));
-					comp_off[i] = static_cast<int64_t>(total);
-					total += (static_cast<size_t>(cbytes[i]) + 63) & ~size_t{ 63 };
+					std::byte* at = static_cast<std::byte*>(where[i]);
+					const std::shared_ptr<std::byte>* owner = nullptr;
+					for (const auto& blk : arenas.blocks)
+						if (at >= blk.first.get() && at < blk.first.get() + blk.second) { owner = &blk.first; break; }
+					if (!owner)
+						throw std::runtime_error("compressed chunk arrived outside the blocks handed to the engine");
+					out[i] = byte_buffer(*owner, at, static_cast<size_t>(cbytes[i]));
 				}
-				// step 2: ONE arena of exactly the compressed size (recycled, page-locked: detail/pinned_pool.h) receives
-				// every chunk by DMA; the chunks are views into it -- no staging area of nominal size, no second copy
-				std::shared_ptr<std::byte> arena = NAMESPACE_COMPRESSED_IMAGE::detail::pinned_pool::get().arena(total);
-				rc = cimg_compress_batch_host_fetch(engine(), static_cast<int32_t>(n), arena.get(), comp_off.data());
-				if (rc < 0)
-					throw std::runtime_error(detail::text("Unable to compress context using Blosc2 with error code ", rc, " (", cimg_last_error(engine()), ")"));
-				for (size_t i = 0; i < n; ++i)
-					out[i] = byte_buffer(arena, arena.get() + comp_off[i], static_cast<size_t>(cbytes[i]));
 				return out;
 			}
 

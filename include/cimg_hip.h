@@ -143,6 +143,16 @@ int cimg_compress_batch_host_begin(cimg_engine* e, const cimg_cparams* p, int32_
                                    const void* h_raw, const int64_t* raw_off, const int32_t* nbytes,
                                    const int32_t* destsize, int32_t* cbytes);
 int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t nchunks, void* h_comp, const int64_t* comp_off);
+/* The same in ONE call, for a caller that wants the chunks in host memory at exactly their compressed sizes (the host mirror's
+ * schunk / image constructors: chunks are std::vector-like buffers of cbytes): the batch runs as a pipeline of groups of about
+ * 16 MiB of pixels, and as soon as the sizes of a group are known the engine asks `alloc(user, bytes)` for a block of host memory
+ * (page-locked for full PCIe speed: cimg_host_malloc) and sends the group's chunks there, packed back to back at 64-byte
+ * boundaries, while the next group is being compressed.  chunk_ptr[i] = where chunk i went (NULL for a chunk that does not fit, cbytes
+ * 0).  Returns when every chunk has arrived.  (cimg_compress_batch_host_begin + _fetch move the chunks only after the LAST group:
+ * 4.2 against 3.0 ms for 4 x 4096^2 float16.) */
+typedef void* (*cimg_alloc_fn)(void* user, size_t bytes);
+int cimg_compress_batch_host_packed(cimg_engine* e, const cimg_cparams* p, int32_t nchunks, const void* h_raw, const int64_t* raw_off,
+                                    const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes, cimg_alloc_fn alloc, void* user, void** chunk_ptr);
 /* Sizes are read from the chunk headers in host memory (the reference passes INT32_MAX as srcsize, wrapper.h:249,
  * so the header is all there is). */
 int cimg_decompress_batch_host(cimg_engine* e, int32_t nchunks,

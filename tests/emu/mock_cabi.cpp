@@ -91,6 +91,35 @@ int cimg_compress_batch_host_fetch(cimg_engine* e, int32_t n, void* h_comp, cons
     return 0;
 }
 
+// (the engine cuts a batch into groups and asks for a block per group: here two groups, so that the host mirror meets chunks in
+// more than one block)
+int cimg_compress_batch_host_packed(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
+                                    const int32_t* nbytes, const int32_t* destsize, int32_t* cbytes, cimg_alloc_fn alloc, void* user, void** chunk_ptr)
+{
+    LOCK_ENGINE(e);
+    if (n <= 0) return 0;
+    if (!alloc || !chunk_ptr) { e->err = "null argument"; return -12; }
+    const int rc = cimg_compress_batch_host_begin(e, p, n, h_raw, raw_off, nbytes, destsize, cbytes);
+    if (rc) return rc;
+    const int cut = n > 1 ? n / 2 : n;
+    for (int g = 0; g < 2; g++) {
+        const int a = g ? cut : 0, b = g ? n : cut;
+        size_t total = 0;
+        for (int i = a; i < b; i++) { if (cbytes[i] < 0) { e->err = "chunk failed to compress"; e->off.clear(); return cbytes[i]; } total += ((size_t)cbytes[i] + 63) & ~(size_t)63; }
+        if (!total) { for (int i = a; i < b; i++) chunk_ptr[i] = nullptr; continue; }
+        uint8_t* block = (uint8_t*)alloc(user, total);
+        if (!block) { e->err = "the caller's allocator returned no memory"; e->off.clear(); return -4; }
+        size_t at = 0;
+        for (int i = a; i < b; i++) {
+            chunk_ptr[i] = cbytes[i] > 0 ? block + at : nullptr;
+            if (cbytes[i] > 0) memcpy(block + at, e->stage.data() + e->off[(size_t)i], (size_t)cbytes[i]);
+            at += ((size_t)cbytes[i] + 63) & ~(size_t)63;
+        }
+    }
+    e->off.clear();
+    return 0;
+}
+
 int cimg_compress_batch_host(cimg_engine* e, const cimg_cparams* p, int32_t n, const void* h_raw, const int64_t* raw_off,
                              const int32_t* nbytes, void* h_comp, const int64_t* comp_off, const int32_t* destsize, int32_t* cbytes)
 {
