@@ -30,6 +30,7 @@ namespace cimg {
 
 #ifdef CIMG_EMULATE
 extern long g_emu_dec_par, g_emu_dec_serial, g_emu_dec_batches;   // test-side statistics only
+extern long g_emu_d2[8];                                          // lz4_decode_wave2: windows, tokens, flushes, rounds, parallel matches, serial matches, scalar sequences, empty windows
 #endif
 
 struct DecodeArgs {
@@ -688,6 +689,440 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
     return op == oend ? 0 : ERR_DATA;
 }
 
+// ---- LZ4 block decode, second form (round 4): tokens first, bytes 63 at a time -------------------------------------------------
+// lz4_decode_wave above does everything window by window: parse 64 input bytes, walk the token chain, place the tokens' output,
+// store literals, copy matches -- and a window of image data holds about thirteen tokens, so the fixed cost of every one of those
+// steps (prefix sum, owner search, dense descriptors, crossbar gathers: 2300 of a window's 4000 cycles) is paid per thirteen tokens.
+// Here a window only FINDS tokens (parse + walk); they are appended, a lane each, to a batch of up to 63 that is executed in one
+// go: ONE prefix sum, the literal runs lane-parallel (16 bytes fetched per lane from the compressed bytes, which still lie ahead of
+// the output: in-place decode keeps the write pointer behind the read pointer, and parsing ahead only reads), the matches in
+// dependency ROUNDS: for every match the range of batch tokens whose output its source touches is found once (two binary searches
+// over the tokens' output positions, crossbar gathers), a match is ready when all of those are done, and all ready matches of a round
+// are copied sixteen a step, four lanes each.  Tokens a batch cannot take (literal runs of 15 bytes or more, matches above 64 bytes,
+// the end of the stream) flush the batch and go through the scalar path of the first form.  Same results, also on damaged streams.
+CIMG_DEV int lz4_decode_wave2(uint8_t* lds, int base, int n, int cs, int csize, int lds_limit)
+{
+    int ip = cs;
+    const int iend = cs + csize;
+    int op = base;
+    const int oend = base + n;
+    int wbase = -4096;
+    LV<uint32_t> win;
+    const int clampmax = (lds_limit - 4) & ~3;
+    LV<uint32_t> pend;
+    int pend_dst = 0, pend_len = 0;
+#define CIMG_RETIRE()                                                                            \
+    do {                                                                                         \
+        if (pend_len) {                                                                          \
+            FOR_LANES_W(l) { if (l < pend_len) lds[pend_dst + l] = (uint8_t)pend[l]; }           \
+            pend_len = 0;                                                                        \
+        }                                                                                        \
+    } while (0)
+#define CIMG_FETCH8(dst, at)                                                                     \
+    do {                                                                                         \
+        const int at_ = (at);                                                                    \
+        if (at_ - wbase > 256 - 12 || at_ < wbase) {                                             \
+            wbase = at_ & ~3;                                                                    \
+            FOR_LANES(l) { win[l] = *reinterpret_cast<const uint32_t*>(lds + imin(wbase + 4 * l, clampmax)); } \
+        }                                                                                        \
+        const int i_ = (at_ - wbase) >> 2;                                                       \
+        const uint64_t d0_ = readlane(win, i_), d1_ = readlane(win, i_ + 1), d2_ = readlane(win, i_ + 2); \
+        const int sh_ = (at_ & 3) * 8;                                                           \
+        dst = ((d0_ | (d1_ << 32)) >> sh_) | (sh_ ? (d2_ << (64 - sh_)) : 0);                    \
+    } while (0)
+#define CIMG_LENEXT(acc)                                                                         \
+    do {                                                                                         \
+        for (;;) {                                                                               \
+            if (ip >= iend) return ERR_DATA;                                                     \
+            LV<uint32_t> eb_;                                                                    \
+            LV<bool> stop_;                                                                      \
+            FOR_LANES(l) {                                                                       \
+                eb_[l] = lds[imin(ip + l, clampmax)];                                            \
+                stop_[l] = (eb_[l] != 255) | (ip + l >= iend);                                   \
+            }                                                                                    \
+            const int f_ = ctz64(ballot(stop_));                                                 \
+            if (f_ < 64) {                                                                       \
+                if (ip + f_ >= iend) return ERR_DATA;                                            \
+                acc += 255 * f_ + (int)readlane(eb_, f_);                                        \
+                ip += f_ + 1;                                                                    \
+                break;                                                                           \
+            }                                                                                    \
+            acc += 255 * 64;                                                                     \
+            ip += 64;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+    // the batch: lane k < cnt is the k-th token found and not yet executed
+    LV<int> TA, TB, TP;                                    // literal count | match length << 8; offset; position of the token byte
+    FOR_LANES(l) { TA[l] = 0; TB[l] = 0; TP[l] = 0; }
+    int cnt = 0;
+    bool force_scalar = false;
+
+    // execute the batch: returns 0 or ERR_DATA
+    auto flush = [&]() -> int {
+        if (cnt == 0) return 0;
+        LV<int> lit, ml, off, len, opos;
+        LV<bool> act;
+        FOR_LANES(l) {
+            act[l] = l < cnt;
+            lit[l] = act[l] ? (TA[l] & 0xFFFF) : 0;
+            ml[l] = act[l] ? (TA[l] >> 16) : 0;
+            off[l] = act[l] ? TB[l] : 1;
+            len[l] = lit[l] + ml[l];
+        }
+        int acc;
+        wave_exscan(len, opos, acc);
+        if (acc > oend - op) {                             // cut at the first token that does not fit: the scalar path meets it next
+            const int room = oend - op;
+            LV<bool> over;
+            FOR_LANES(l) { over[l] = act[l] & (opos[l] + len[l] > room); }
+            const int f = ctz64(ballot(over));
+            ip = readlane(TP, f);
+            cnt = f;
+            acc = readlane(opos, f);
+            force_scalar = true;
+            FOR_LANES(l) { act[l] = l < cnt; if (!act[l]) { lit[l] = 0; ml[l] = 0; off[l] = 1; } }
+            if (cnt == 0) return 0;
+        }
+        LV<int> P, D, S;
+        LV<bool> badv;
+        FOR_LANES(l) {
+            P[l] = act[l] ? op + opos[l] : 0x7FFFFFFF;     // (lanes behind the batch: beyond every position the searches ask for)
+            D[l] = op + opos[l] + lit[l];
+            S[l] = D[l] - off[l];
+            badv[l] = act[l] & (S[l] < base);
+        }
+        if (ballot(badv)) return ERR_DATA;
+        // ---- literals: the bytes behind the token byte (and its length byte, from 15 literals on).  Every lane fetches the first 16
+        // bytes of its run; runs longer than that are finished one after the other, in token order, by the whole wave; then every
+        // lane stores its first bytes.  (The output of a token may lie on the compressed bytes of the tokens in front of it -- never on
+        // those behind: all first pieces are in registers before anything is written, and the long runs go in order.)
+        {
+            LV<u128> v;
+            LV<int> lsrc;
+            LV<bool> longer;
+            FOR_LANES(l) {
+                lsrc[l] = TP[l] + 1 + (lit[l] >= 15 ? 1 : 0);
+                longer[l] = act[l] & (lit[l] > 16);
+                const int sa = imin(lsrc[l], clampmax);
+                const int a = sa & ~3;
+                const uint32_t sh = (uint32_t)sa & 3u;
+                const uint32_t q0 = *reinterpret_cast<const uint32_t*>(lds + imin(a, clampmax));
+                const uint32_t q1 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 4, clampmax));
+                const uint32_t q2 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 8, clampmax));
+                const uint32_t q3 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 12, clampmax));
+                const uint32_t q4 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 16, clampmax));
+                v[l].x = alignbyte(q1, q0, sh); v[l].y = alignbyte(q2, q1, sh); v[l].z = alignbyte(q3, q2, sh); v[l].w = alignbyte(q4, q3, sh);
+            }
+            uint64_t todo = ballot(longer);
+            while (todo) {
+                const int t = ctz64(todo);
+                todo &= todo - 1;
+                lds_copy_bytes(lds, readlane(P, t) + 16, readlane(lsrc, t) + 16, readlane(lit, t) - 16);
+            }
+            FOR_LANES_W(l) {
+                const int nlit = act[l] ? imin(lit[l], 16) : 0;
+                uint8_t* d = lds + (act[l] ? P[l] : base);
+                const uint32_t w4[4] = {v[l].x, v[l].y, v[l].z, v[l].w};
+                CIMG_UNROLL
+                for (int j = 0; j < 4; j++) { if (nlit >= 4 * j + 4) lds_st32u(d + 4 * j, w4[j]); }
+                const int t = nlit & ~3;
+                const uint32_t last = t < 16 ? w4[(t >> 2) & 3] : 0;
+                CIMG_UNROLL
+                for (int k = 0; k < 3; k++) { if (nlit > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+            }
+        }
+        // ---- matches.  Which batch tokens does a match's source touch?  need = the bytes it reads before writing (a fill reads
+        // one, a match that overlaps itself its first `offset`); cntP(x) = tokens whose output starts at or below x.
+        LV<bool> hasm, ovl;
+        LV<int> lo_i, hi_i;
+        {
+            LV<int> ca, cb, xa, xb;
+            FOR_LANES(l) {
+                hasm[l] = act[l] & (ml[l] > 0);
+                ovl[l] = hasm[l] & (((off[l] < ml[l]) & (off[l] != 1)) | (ml[l] > 64));      // copied by the whole wave, in its turn
+                const int need = off[l] == 1 ? 1 : (off[l] < ml[l] ? off[l] : ml[l]);
+                xa[l] = S[l]; xb[l] = S[l] + need - 1;
+                ca[l] = 0; cb[l] = 0;
+            }
+            CIMG_UNROLL
+            for (int k = 5; k >= 0; --k) {
+                LV<int> ta, tb, pa, pb;
+                FOR_LANES(l) { ta[l] = ca[l] + (1 << k) - 1; tb[l] = cb[l] + (1 << k) - 1; }     // index of the (count + 2^k)-th token
+                lane_gather(P, ta, pa);
+                lane_gather(P, tb, pb);
+                FOR_LANES(l) {
+                    if (ta[l] < 64 && pa[l] <= xa[l]) ca[l] += 1 << k;
+                    if (tb[l] < 64 && pb[l] <= xb[l]) cb[l] += 1 << k;
+                }
+            }
+            // tokens ja = ca - 1 .. jb = cb - 1 produce the source bytes (ca == 0: the source begins in front of the batch); the match
+            // waits for the MATCHES of those below itself (their literals are in place; its own literals too)
+            FOR_LANES(l) {
+                lo_i[l] = ca[l] > 0 ? ca[l] - 1 : 0;
+                hi_i[l] = imin(cb[l] - 1, l - 1);
+            }
+        }
+        uint64_t done = ~ballot(hasm);
+#ifdef CIMG_EMULATE
+        g_emu_d2[2]++;
+#endif
+        for (int round = 0; round < 128 && ~done; ++round) {
+            LV<bool> ready;
+            FOR_LANES(l) {
+                const uint64_t upto = hi_i[l] >= 63 ? ~0ull : ((1ull << (hi_i[l] + 1)) - 1);
+                const uint64_t from = lo_i[l] >= 64 ? 0ull : (~0ull << lo_i[l]);
+                const uint64_t deps = hi_i[l] >= lo_i[l] ? (upto & from) : 0ull;
+                ready[l] = !((done >> l) & 1) & ((deps & ~done) == 0) & !ovl[l];
+            }
+            const uint64_t rmask = ballot(ready);
+            // (one or two ready matches: the wave-wide copy of the FIRST pending match below is cheaper than the dense-descriptor
+            // machinery -- that match is always executable: everything it depends on lies below it and is done)
+#ifdef CIMG_EMULATE
+            g_emu_d2[3]++; if (popc64(rmask) >= 3) g_emu_d2[4] += popc64(rmask); else g_emu_d2[5]++;
+#endif
+            if (popc64(rmask) >= 3) {
+                const int R = popc64(rmask);
+                LV<int> rank, d0, d1, D0, D1;
+                FOR_LANES(l) {
+                    rank[l] = ready[l] ? lane_rank(rmask, l) : 63;   // (a batch has at most 63 tokens: slot 63 is nobody's)
+                    d0[l] = D[l] | (ml[l] << 18);
+                    d1[l] = S[l] | (off[l] == 1 ? 1 << 18 : 0);
+                }
+                lane_scatter(d0, rank, D0);
+                lane_scatter(d1, rank, D1);
+                for (int g = 0; g < R; g += 16) {
+                    LV<int> who, e0, e1;
+                    FOR_LANES(l) { who[l] = g + (l >> 2); }
+                    lane_gather(D0, who, e0);
+                    lane_gather(D1, who, e1);
+                    LV<u128> w;
+                    FOR_LANES(l) {
+                        const bool on = who[l] < R;
+                        const bool f = (e1[l] >> 18) & 1;
+                        const int sa = on ? (e1[l] & 0x3FFFF) + (f ? 0 : (l & 3) * 16) : base;
+                        const int a = sa & ~3;
+                        const uint32_t sh = (uint32_t)sa & 3u;
+                        const uint32_t q0 = *reinterpret_cast<const uint32_t*>(lds + a);
+                        const uint32_t q1 = *reinterpret_cast<const uint32_t*>(lds + a + 4);
+                        const uint32_t q2 = *reinterpret_cast<const uint32_t*>(lds + a + 8);
+                        const uint32_t q3 = *reinterpret_cast<const uint32_t*>(lds + a + 12);
+                        const uint32_t q4 = *reinterpret_cast<const uint32_t*>(lds + a + 16);
+                        const uint32_t x0 = alignbyte(q1, q0, sh);
+                        const uint32_t fb = (x0 & 0xFF) * 0x01010101u;
+                        w[l].x = f ? fb : x0;
+                        w[l].y = f ? fb : alignbyte(q2, q1, sh);
+                        w[l].z = f ? fb : alignbyte(q3, q2, sh);
+                        w[l].w = f ? fb : alignbyte(q4, q3, sh);
+                    }
+                    FOR_LANES_W(l) {
+                        const int rem = who[l] < R ? ((e0[l] >> 18) & 0x7F) - (l & 3) * 16 : 0;
+                        uint8_t* d = lds + (e0[l] & 0x3FFFF) + (l & 3) * 16;
+                        const uint32_t v4[4] = {w[l].x, w[l].y, w[l].z, w[l].w};
+                        CIMG_UNROLL
+                        for (int j = 0; j < 4; j++) { if (rem >= 4 * j + 4) lds_st32u(d + 4 * j, v4[j]); }
+                        const int t = rem > 0 ? (rem > 16 ? 16 : rem) & ~3 : 0;
+                        const uint32_t last = t < 16 ? v4[(t >> 2) & 3] : 0;
+                        CIMG_UNROLL
+                        for (int k = 0; k < 3; k++) { if (rem > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+                    }
+                }
+                done |= rmask;
+            } else {
+                // the first match not done: everything it depends on lies below it and is done
+                const int t = ctz64(~done);
+                const int dst = readlane(D, t), src = readlane(S, t), mlen = readlane(ml, t);
+                const int offset = dst - src;
+                if (mlen <= 64) {
+                    LV<uint32_t> mv;
+                    if (offset >= mlen) { FOR_LANES(l) { mv[l] = lds[src + (l < mlen ? l : 0)]; } }
+                    else if (offset == 1) { FOR_LANES(l) { mv[l] = lds[src]; } }
+                    else {
+                        const float inv = fast_rcp((float)offset);
+                        FOR_LANES(l) { mv[l] = lds[src + small_mod(l < mlen ? l : 0, offset, inv)]; }
+                    }
+                    FOR_LANES_W(l) { if (l < mlen) lds[dst + l] = (uint8_t)mv[l]; }
+                } else {
+                    lds_copy_match(lds, dst, src, mlen);
+                }
+                done |= 1ull << t;
+            }
+        }
+        op += acc;
+        cnt = 0;
+        return 0;
+    };
+
+    for (;;) {
+        if (ip >= iend) return ERR_DATA;
+        // ---- a window of tokens: parse every "simple" sequence of the next 64 input bytes, walk the chain, append them to the batch
+        if (iend - ip >= 24 && !force_scalar) {
+            LV<uint32_t> tb, o0, o1, ex;
+            LV<int> lit_l, walk_l, off_l, ml_l;
+            LV<bool> good;
+            enum : int { WALK_BAD = 0x2000 };
+            LV<int> lsrc_l;
+            LV<bool> litok;
+            FOR_LANES(l) {
+                const int at = ip + l;
+                tb[l] = lds[imin(at, clampmax)];
+                const uint32_t lb = lds[imin(at + 1, clampmax)];     // literal-length byte, meaningful when the nibble is 15
+                const int litn = (int)(tb[l] >> 4);
+                const bool lext = litn == 15;
+                lit_l[l] = lext ? 15 + (int)lb : litn;
+                litok[l] = !lext | (lb < 255);
+                lsrc_l[l] = l + (lext ? 2 : 1);
+                const int hp = imin(ip + lsrc_l[l] + lit_l[l], clampmax);
+                o0[l] = lds[hp];
+                o1[l] = lds[hp + 1];
+                ex[l] = lds[hp + 2];
+            }
+            // The walk only needs where the next token starts -- token byte and literal-length byte, the FIRST round trip.  The offset and
+            // the match-length byte (second round trip, requested above) arrive while the chain is walked; a token they disqualify
+            // (offset 0, a second length byte) cuts the chain afterwards.
+            FOR_LANES(l) {
+                const bool has_ext = (tb[l] & 15) == 15;
+                const int nxt = lsrc_l[l] + lit_l[l] + 2 + (has_ext ? 1 : 0);
+                walk_l[l] = (litok[l] & (ip + nxt < iend)) ? nxt : (int)WALK_BAD;
+            }
+            uint64_t tokens = 0;
+            int s = 0, t_ = 0;
+#define CIMG_WALK_STEP t_ = readlane(walk_l, s); if (t_ > 63) break; tokens |= 1ull << s; s = t_;
+            for (int rnd = 0; rnd < 3; ++rnd) {
+                CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP CIMG_WALK_STEP
+            }
+#undef CIMG_WALK_STEP
+            if (t_ > 63 && !(t_ & WALK_BAD)) { tokens |= 1ull << s; s = t_; }
+            FOR_LANES(l) {
+                const int mln = (int)(tb[l] & 15);
+                const bool has_ext = mln == 15;
+                off_l[l] = (int)(o0[l] | (o1[l] << 8));
+                ml_l[l] = mln + 4 + (has_ext ? (int)ex[l] : 0);
+                good[l] = (!has_ext | (ex[l] < 255)) & (off_l[l] != 0);
+            }
+            {
+                const uint64_t unfit = tokens & ~ballot(good);
+                if (unfit) { const int f0 = ctz64(unfit); tokens &= (1ull << f0) - 1; s = f0; }
+            }
+#ifdef CIMG_EMULATE
+            g_emu_d2[0]++; g_emu_d2[1] += popc64(tokens); if (!tokens) g_emu_d2[7]++;
+#endif
+            if (tokens) {
+                const int k = popc64(tokens);
+                if (cnt + k > 63) { const int rc = flush(); if (rc) return rc; if (force_scalar) continue; }
+                LV<int> slot, a0, a1, a2, A0, A1, A2;
+                FOR_LANES(l) {
+                    const bool is = (tokens >> l) & 1;
+                    slot[l] = is ? cnt + lane_rank(tokens, l) : 63;
+                    a0[l] = lit_l[l] | (ml_l[l] << 16);
+                    a1[l] = off_l[l];
+                    a2[l] = ip + l;
+                }
+                lane_scatter(a0, slot, A0);
+                lane_scatter(a1, slot, A1);
+                lane_scatter(a2, slot, A2);
+                FOR_LANES(l) {
+                    const bool mine = (l >= cnt) & (l < cnt + k);
+                    TA[l] = mine ? A0[l] : TA[l]; TB[l] = mine ? A1[l] : TB[l]; TP[l] = mine ? A2[l] : TP[l];
+                }
+                cnt += k;
+                ip += s;
+                continue;
+            }
+        }
+        // ---- one sequence the scalar way (lz4_decode_wave's): everything found so far is executed first
+        if (cnt) { const int rc = flush(); if (rc) return rc; if (force_scalar && ip >= iend) return ERR_DATA; }
+        force_scalar = false;
+#ifdef CIMG_EMULATE
+        g_emu_d2[6]++;
+#endif
+        uint64_t q;
+        CIMG_FETCH8(q, ip);
+        const uint32_t token = (uint32_t)(q & 0xFF);
+        int lit = (int)(token >> 4);
+        int ml = (int)(token & 15);
+        int offset;
+        const bool ext = ml == 15;
+        if ((lit <= 4 || (lit == 5 && !ext)) && iend - ip >= 8) {
+            const int hdr = 1 + lit + 2;
+            offset = (int)((q >> (8 * (1 + lit))) & 0xFFFF);
+            int extra = 0;
+            if (ext) {
+                extra = (int)((q >> (8 * hdr)) & 0xFF);
+                if (extra == 255) {
+                    ip += hdr + 1;
+                    ml += 255;
+                    CIMG_LENEXT(ml);
+                    extra = -1;
+                } else {
+                    ml += extra;
+                }
+            }
+            if (extra >= 0) ip += hdr + (ext ? 1 : 0);
+            if (lit > oend - op) return ERR_DATA;
+            CIMG_RETIRE();
+            if (lit) {
+                const uint64_t lits = q >> 8;
+                FOR_LANES_W(l) { if (l < lit) lds[op + l] = (uint8_t)(lits >> (8 * (l & 7))); }
+                op += lit;
+            }
+        } else {
+            CIMG_RETIRE();
+            ip++;
+            if (lit == 15) {
+                CIMG_LENEXT(lit);
+            }
+            if (lit > iend - ip || lit > oend - op) return ERR_DATA;
+            if (lit > 0) {
+                if (lit >= 512) lds_copy_wide(lds, op, ip, lit); else lds_copy_bytes(lds, op, ip, lit);
+                ip += lit;
+                op += lit;
+            }
+            if (ip == iend) break;
+            if (iend - ip < 2) return ERR_DATA;
+            uint64_t e;
+            CIMG_FETCH8(e, ip);
+            offset = (int)(e & 0xFFFF);
+            ip += 2;
+            if (ext) {
+                CIMG_LENEXT(ml);
+            }
+        }
+        if (ip > iend) return ERR_DATA;
+        if (offset == 0 || offset > op - base) return ERR_DATA;
+        ml += 4;
+        if (ml > oend - op) return ERR_DATA;
+        const int src = op - offset;
+        if (ml <= 64) {
+            if (offset >= ml) {
+                FOR_LANES(l) { pend[l] = lds[src + (l < ml ? l : 0)]; }
+            } else if (offset == 1) {
+                FOR_LANES(l) { pend[l] = lds[src]; }
+            } else {
+                const float inv = fast_rcp((float)offset);
+                FOR_LANES(l) { pend[l] = lds[src + small_mod(l < ml ? l : 0, offset, inv)]; }
+            }
+            pend_dst = op;
+            pend_len = ml;
+            CIMG_RETIRE();                                     // (the next thing may be a window of tokens: nothing stays pending)
+        } else {
+            lds_copy_match(lds, op, src, ml);
+        }
+        op += ml;
+    }
+    CIMG_RETIRE();
+#undef CIMG_FETCH8
+#undef CIMG_LENEXT
+#undef CIMG_RETIRE
+    return op == oend ? 0 : ERR_DATA;
+}
+
+#ifdef CIMG_LZ4_DECODE_V1
+#define CIMG_LZ4_DECODE lz4_decode_wave
+#else
+#define CIMG_LZ4_DECODE lz4_decode_wave2
+#endif
+
 // ---- byte-plane helpers ----------------------------------------------------------------------------
 #ifdef CIMG_EMULATE
 inline uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel)
@@ -788,8 +1223,13 @@ struct DecodeBlock {
                 } else {
                     const int park = base + rs - round16(cs);
                     wave_copy_g2l(c + pos, lds, park, cs);
+#ifdef CIMG_PROFILE
                     const int rc = fmt == 0 ? blosclz_decode_wave(lds, base, neblock, park, cs, a.lds_bytes)
                                             : lz4_decode_wave(lds, base, neblock, park, cs, a.lds_bytes, a.dbg, b);
+#else
+                    const int rc = fmt == 0 ? blosclz_decode_wave(lds, base, neblock, park, cs, a.lds_bytes)
+                                            : CIMG_LZ4_DECODE(lds, base, neblock, park, cs, a.lds_bytes);
+#endif
                     if (rc < 0) fail(rc);
                 }
             }

@@ -226,7 +226,7 @@ struct DecodeLeanWave {
                                   : lz4_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes, a.dbg, h.b);
 #else
         const int rc = h.fmt == 0 ? blosclz_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes)
-                                  : lz4_decode_wave(lds, 0, neblock, park, lz_cs, a.lds_bytes);
+                                  : CIMG_LZ4_DECODE(lds, 0, neblock, park, lz_cs, a.lds_bytes);
 #endif
         return rc >= 0;
     }

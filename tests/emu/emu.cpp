@@ -21,6 +21,7 @@
 #endif
 
 namespace cimg { long g_emu_zx_batches = 0, g_emu_zx_rounds = 0, g_emu_zx_par = 0, g_emu_zx_serial = 0, g_emu_zx_longlit = 0; }
+namespace cimg { long g_emu_d2[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
 namespace cimg { long g_emu_dec_par = 0, g_emu_dec_serial = 0, g_emu_dec_batches = 0; int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
 static int g_emu_block_items = 1;     // tests also run the one-item-per-plane form
@@ -229,6 +230,7 @@ int emu_zstd_encode(const uint8_t* src, int n, uint8_t* dst, int cap)
 // one zstd frame through csrc/zstd_decode.h (the work area the kernel keeps in LDS is on the heap here), the ways the kernel
 // uses it: the frame as a copy the decoder reads in place (tail = 0), and the frame "in global memory" (tail = 1) with a stage
 // like the kernel's and with one so small that most sections are read where they lie.  All must agree; -999 says they did not.
+void emu_d2_stats(long* out) { for (int i = 0; i < 8; i++) { out[i] = g_emu_d2[i]; g_emu_d2[i] = 0; } }
 void emu_zstd_exec_stats(long* out) { out[0] = g_emu_zx_batches; out[1] = g_emu_zx_rounds; out[2] = g_emu_zx_par; out[3] = g_emu_zx_serial; out[4] = g_emu_zx_longlit;
     g_emu_zx_batches = g_emu_zx_rounds = g_emu_zx_par = g_emu_zx_serial = g_emu_zx_longlit = 0; }
 int emu_zstd_decode(const uint8_t* src, int csize, uint8_t* dst, int cap)
@@ -270,6 +272,11 @@ int emu_lz4_decode(const uint8_t* src, int csize, uint8_t* dst, int n)
     const int park = rs - round16(csize);
     memcpy(lds.data() + park, src, (size_t)csize);
     const int rc = lz4_decode_wave(lds.data(), 0, n, park, csize, rs + 32);
+    // (the second form of the decoder -- tokens first, bytes 63 at a time -- on the same stream: it must agree, also on damaged ones)
+    std::vector<uint8_t> lds2((size_t)rs + 32 + EMU_LDS_SLACK, 0xCD);
+    memcpy(lds2.data() + park, src, (size_t)csize);
+    const int rc2 = lz4_decode_wave2(lds2.data(), 0, n, park, csize, rs + 32);
+    if ((rc >= 0) != (rc2 >= 0) || (rc >= 0 && memcmp(lds.data(), lds2.data(), (size_t)n))) return -999;
     memcpy(dst, lds.data(), (size_t)n);
     return rc;
 }
