@@ -26,7 +26,8 @@ enum : int {
     ERR_RUN_LENGTH = -17, ERR_MAX_BUFSIZE = -26,
     // internal, never returned to a caller: cimg_decode_blocks met a zstd chunk (codec format 4), which cimg_decode_zstd reads
     // (engine.hip: decompress_finish clears exactly these words before that launch)
-    STATUS_ZSTD_PENDING = -1000,
+    STATUS_ZSTD_PENDING = -1000,            // ... whose blocks are one stream each (one wave per block)
+    STATUS_ZSTD_PENDING_SPLIT = -1001,      // ... whose blocks are split into one stream per byte of the element (two waves per block)
 };
 
 // one per chunk of a batch; built by the host (engine.cpp: plan_chunk)

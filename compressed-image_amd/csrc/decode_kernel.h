@@ -25,6 +25,7 @@
 #pragma once
 #include "codec_types.h"
 #include "wave.h"
+#include <type_traits>
 
 namespace cimg {
 
@@ -689,6 +690,234 @@ CIMG_DEV int lz4_decode_wave(uint8_t* lds, int base, int n, int cs, int csize, i
     return op == oend ? 0 : ERR_DATA;
 }
 
+// ---- a batch of up to 63 tokens, executed at once (shared by lz4_decode_wave2 and the zstd executor) --------------------------------
+// Token k < cnt: lit[k] literal bytes at offset lsrc[k], then a match of ml[k] bytes at distance off[k] (ml 0: none).  All
+// offsets are relative to `lds` (MP: a generic pointer, or an address-space-3 one where the compiler cannot see that it is LDS);
+// [base, oend) is the output, clampmax the last dword that may be READ.  op: where the batch's output starts (moved behind it).
+// A batch that would overrun oend is executed up to the first token that does not fit: cut_out = its index (-1: none).
+// Returns 0, or ERR_DATA for a match that reaches in front of `base`.
+#define LZ_LD32(p) (*(LZ_WP)(p))
+#define LZ_ST32(p, v) do { const uint32_t v_ = (v); __builtin_memcpy((p), &v_, 4); } while (0)
+template <class MP, bool CLAMP = false>
+CIMG_DEV int lz_batch_execute(MP lds, int base, int oend, int clampmax, int& op, int cnt_in, const LV<int>& lit_in, const LV<int>& ml_in,
+                              const LV<int>& off_in, const LV<int>& lsrc_in, int& cut_out)
+{
+    using LZ_WP = typename std::conditional<std::is_same<MP, uint8_t*>::value, const uint32_t*, cimg_lds_cu32p>::type;
+cut_out = -1;
+int cnt = cnt_in;
+if (cnt == 0) return 0;
+LV<int> lit, ml, off, len, opos;
+LV<bool> act;
+FOR_LANES(l) {
+    act[l] = l < cnt;
+    lit[l] = act[l] ? lit_in[l] : 0;
+    ml[l] = act[l] ? ml_in[l] : 0;
+    off[l] = act[l] ? off_in[l] : 1;
+    len[l] = lit[l] + ml[l];
+}
+    int acc;
+    wave_exscan(len, opos, acc);
+    if (acc > oend - op) {                             // cut at the first token that does not fit: the scalar path meets it next
+        const int room = oend - op;
+        LV<bool> over;
+        FOR_LANES(l) { over[l] = act[l] & (opos[l] + len[l] > room); }
+        const int f = ctz64(ballot(over));
+        cut_out = f;
+        cnt = f;
+        acc = readlane(opos, f);
+        FOR_LANES(l) { act[l] = l < cnt; if (!act[l]) { lit[l] = 0; ml[l] = 0; off[l] = 1; } }
+        if (cnt == 0) return 0;
+    }
+    LV<int> P, D, S;
+    LV<bool> badv;
+    FOR_LANES(l) {
+        P[l] = act[l] ? op + opos[l] : 0x7FFFFFFF;     // (lanes behind the batch: beyond every position the searches ask for)
+        D[l] = op + opos[l] + lit[l];
+        S[l] = D[l] - off[l];
+        badv[l] = act[l] & (S[l] < base);
+    }
+    if (ballot(badv)) return ERR_DATA;
+    // ---- literals: the bytes behind the token byte (and its length byte, from 15 literals on).  Every lane fetches the first 16
+    // bytes of its run; runs longer than that are finished one after the other, in token order, by the whole wave; then every
+    // lane stores its first bytes.  (The output of a token may lie on the compressed bytes of the tokens in front of it -- never on
+    // those behind: all first pieces are in registers before anything is written, and the long runs go in order.)
+    {
+        LV<u128> v;
+        LV<int> lsrc;
+        LV<bool> longer;
+        FOR_LANES(l) {
+            lsrc[l] = lsrc_in[l];
+            longer[l] = act[l] & (lit[l] > 16);
+            const int sa = lsrc[l] > 0 ? lsrc[l] : 0;            // (the dword addresses are clamped, not the position: a run may END at the last readable byte)
+            const int a = sa & ~3;
+            const uint32_t sh = (uint32_t)sa & 3u;
+            const uint32_t q0 = LZ_LD32(lds + imin(a, clampmax));
+            const uint32_t q1 = LZ_LD32(lds + imin(a + 4, clampmax));
+            const uint32_t q2 = LZ_LD32(lds + imin(a + 8, clampmax));
+            const uint32_t q3 = LZ_LD32(lds + imin(a + 12, clampmax));
+            const uint32_t q4 = LZ_LD32(lds + imin(a + 16, clampmax));
+            v[l].x = alignbyte(q1, q0, sh); v[l].y = alignbyte(q2, q1, sh); v[l].z = alignbyte(q3, q2, sh); v[l].w = alignbyte(q4, q3, sh);
+        }
+        uint64_t todo = ballot(longer);
+        while (todo) {
+            const int t = ctz64(todo);
+            todo &= todo - 1;
+            lds_copy_bytes((uint8_t*)lds, readlane(P, t) + 16, readlane(lsrc, t) + 16, readlane(lit, t) - 16);
+        }
+        FOR_LANES_W(l) {
+            const int nlit = act[l] ? imin(lit[l], 16) : 0;
+            MP d = lds + (act[l] ? P[l] : base);
+            const uint32_t w4[4] = {v[l].x, v[l].y, v[l].z, v[l].w};
+            CIMG_UNROLL
+            for (int j = 0; j < 4; j++) { if (nlit >= 4 * j + 4) LZ_ST32(d + 4 * j, w4[j]); }
+            const int t = nlit & ~3;
+            const uint32_t last = t < 16 ? w4[(t >> 2) & 3] : 0;
+            CIMG_UNROLL
+            for (int k = 0; k < 3; k++) { if (nlit > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+        }
+    }
+    // ---- matches.  Which batch tokens does a match's source touch?  need = the bytes it reads before writing (a fill reads
+    // one, a match that overlaps itself its first `offset`); cntP(x) = tokens whose output starts at or below x.
+    LV<bool> hasm, ovl;
+    LV<int> lo_i, hi_i;
+    {
+        LV<int> ca, cb, xa, xb;
+        FOR_LANES(l) {
+            hasm[l] = act[l] & (ml[l] > 0);
+            ovl[l] = hasm[l] & (((off[l] < ml[l]) & (off[l] != 1)) | (ml[l] > 64));      // copied by the whole wave, in its turn
+            const int need = off[l] == 1 ? 1 : (off[l] < ml[l] ? off[l] : ml[l]);
+            xa[l] = S[l]; xb[l] = S[l] + need - 1;
+            ca[l] = 0; cb[l] = 0;
+        }
+        CIMG_UNROLL
+        for (int k = 5; k >= 0; --k) {
+            LV<int> ta, tb, pa, pb;
+            FOR_LANES(l) { ta[l] = ca[l] + (1 << k) - 1; tb[l] = cb[l] + (1 << k) - 1; }     // index of the (count + 2^k)-th token
+            lane_gather(P, ta, pa);
+            lane_gather(P, tb, pb);
+            FOR_LANES(l) {
+                if (ta[l] < 64 && pa[l] <= xa[l]) ca[l] += 1 << k;
+                if (tb[l] < 64 && pb[l] <= xb[l]) cb[l] += 1 << k;
+            }
+        }
+        // tokens ja = ca - 1 .. jb = cb - 1 produce the source bytes (ca == 0: the source begins in front of the batch); the match
+        // waits for the MATCHES of those below itself (their literals are in place; its own literals too)
+        FOR_LANES(l) {
+            lo_i[l] = ca[l] > 0 ? ca[l] - 1 : 0;
+            hi_i[l] = imin(cb[l] - 1, l - 1);
+        }
+    }
+    uint64_t done = ~ballot(hasm);
+#ifdef CIMG_EMULATE
+    g_emu_d2[2]++;
+#endif
+    for (int round = 0; round < 128 && ~done; ++round) {
+        LV<bool> ready;
+        FOR_LANES(l) {
+            const uint64_t upto = hi_i[l] >= 63 ? ~0ull : ((1ull << (hi_i[l] + 1)) - 1);
+            const uint64_t from = lo_i[l] >= 64 ? 0ull : (~0ull << lo_i[l]);
+            const uint64_t deps = hi_i[l] >= lo_i[l] ? (upto & from) : 0ull;
+            ready[l] = !((done >> l) & 1) & ((deps & ~done) == 0) & !ovl[l];
+        }
+        const uint64_t rmask = ballot(ready);
+        // (one or two ready matches: the wave-wide copy of the FIRST pending match below is cheaper than the dense-descriptor
+        // machinery -- that match is always executable: everything it depends on lies below it and is done)
+#ifdef CIMG_EMULATE
+        g_emu_d2[3]++; if (popc64(rmask) >= 3) g_emu_d2[4] += popc64(rmask); else g_emu_d2[5]++;
+#endif
+        if (popc64(rmask) >= 3) {
+            const int R = popc64(rmask);
+            LV<int> rank, d0, d1, D0, D1;
+            FOR_LANES(l) {
+                rank[l] = ready[l] ? lane_rank(rmask, l) : 63;   // (a batch has at most 63 tokens: slot 63 is nobody's)
+                d0[l] = D[l] | ((ready[l] ? ml[l] : 0) << 18);            // (a ready match has at most 64 bytes)
+                d1[l] = S[l] | (off[l] == 1 ? 1 << 18 : 0);
+            }
+            lane_scatter(d0, rank, D0);
+            lane_scatter(d1, rank, D1);
+            for (int g = 0; g < R; g += 16) {
+                LV<int> who, e0, e1;
+                FOR_LANES(l) { who[l] = g + (l >> 2); }
+                lane_gather(D0, who, e0);
+                lane_gather(D1, who, e1);
+                LV<u128> w;
+                FOR_LANES(l) {
+                    const bool on = who[l] < R;
+                    const bool f = (e1[l] >> 18) & 1;
+                    const int sa = on ? (e1[l] & 0x3FFFF) + (f ? 0 : (l & 3) * 16) : base;
+                    const int a = sa & ~3;
+                    const uint32_t sh = (uint32_t)sa & 3u;
+                    // (CLAMP: the output may end where readable memory ends -- the zstd executor in the host tests; the LZ4 planes
+                    // have their in-place margin behind them)
+                    const uint32_t q0 = LZ_LD32(lds + (CLAMP ? imin(a, clampmax) : a));
+                    const uint32_t q1 = LZ_LD32(lds + (CLAMP ? imin(a + 4, clampmax) : a + 4));
+                    const uint32_t q2 = LZ_LD32(lds + (CLAMP ? imin(a + 8, clampmax) : a + 8));
+                    const uint32_t q3 = LZ_LD32(lds + (CLAMP ? imin(a + 12, clampmax) : a + 12));
+                    const uint32_t q4 = LZ_LD32(lds + (CLAMP ? imin(a + 16, clampmax) : a + 16));
+                    const uint32_t x0 = alignbyte(q1, q0, sh);
+                    const uint32_t fb = (x0 & 0xFF) * 0x01010101u;
+                    w[l].x = f ? fb : x0;
+                    w[l].y = f ? fb : alignbyte(q2, q1, sh);
+                    w[l].z = f ? fb : alignbyte(q3, q2, sh);
+                    w[l].w = f ? fb : alignbyte(q4, q3, sh);
+                }
+                FOR_LANES_W(l) {
+                    const int rem = who[l] < R ? ((e0[l] >> 18) & 0x7F) - (l & 3) * 16 : 0;
+                    MP d = lds + (e0[l] & 0x3FFFF) + (l & 3) * 16;
+                    const uint32_t v4[4] = {w[l].x, w[l].y, w[l].z, w[l].w};
+                    CIMG_UNROLL
+                    for (int j = 0; j < 4; j++) { if (rem >= 4 * j + 4) LZ_ST32(d + 4 * j, v4[j]); }
+                    const int t = rem > 0 ? (rem > 16 ? 16 : rem) & ~3 : 0;
+                    const uint32_t last = t < 16 ? v4[(t >> 2) & 3] : 0;
+                    CIMG_UNROLL
+                    for (int k = 0; k < 3; k++) { if (rem > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
+                }
+            }
+            done |= rmask;
+        } else {
+            // the first match not done: everything it depends on lies below it and is done
+            const int t = ctz64(~done);
+            const int dst = readlane(D, t), src = readlane(S, t), mlen = readlane(ml, t);
+            const int offset = dst - src;
+            if (mlen <= 64) {
+                LV<uint32_t> mv;
+                if (offset >= mlen) { FOR_LANES(l) { mv[l] = lds[src + (l < mlen ? l : 0)]; } }
+                else if (offset == 1) { FOR_LANES(l) { mv[l] = lds[src]; } }
+                else {
+                    const float inv = fast_rcp((float)offset);
+                    FOR_LANES(l) { mv[l] = lds[src + small_mod(l < mlen ? l : 0, offset, inv)]; }
+                }
+                FOR_LANES_W(l) { if (l < mlen) lds[dst + l] = (uint8_t)mv[l]; }
+            } else if (CLAMP) {
+                // (byte-exact: nothing is read outside [src, dst + mlen) -- a step of 64 reads in front of what it writes when the
+                // offset is at least 64 or the match does not overlap itself; else the pattern in front of dst is repeated)
+                if (offset >= 64 || offset >= mlen) {
+                    for (int k0 = 0; k0 < mlen; k0 += 64) {
+                        LV<uint32_t> mv;
+                        FOR_LANES(l) { mv[l] = lds[src + k0 + (k0 + l < mlen ? l : 0)]; }
+                        FOR_LANES_W(l) { if (k0 + l < mlen) lds[dst + k0 + l] = (uint8_t)mv[l]; }
+                    }
+                } else {
+                    for (int k0 = 0; k0 < mlen; k0 += 64) {
+                        LV<uint32_t> mv;
+                        FOR_LANES(l) { mv[l] = lds[src + (k0 + l) % offset]; }
+                        FOR_LANES_W(l) { if (k0 + l < mlen) lds[dst + k0 + l] = (uint8_t)mv[l]; }
+                    }
+                }
+            } else {
+                lds_copy_match((uint8_t*)lds, dst, src, mlen);
+            }
+            done |= 1ull << t;
+        }
+    }
+    op += acc;
+    return 0;
+}
+
+
+#undef LZ_LD32
+#undef LZ_ST32
+
 // ---- LZ4 block decode, second form (round 4): tokens first, bytes 63 at a time -------------------------------------------------
 // lz4_decode_wave above does everything window by window: parse 64 input bytes, walk the token chain, place the tokens' output,
 // store literals, copy matches -- and a window of image data holds about thirteen tokens, so the fixed cost of every one of those
@@ -759,198 +988,20 @@ CIMG_DEV int lz4_decode_wave2(uint8_t* lds, int base, int n, int cs, int csize, 
     bool force_scalar = false;
 
     // execute the batch: returns 0 or ERR_DATA
+    // execute the batch (lz_batch_execute); a batch cut short puts the read position back on the token that did not fit
     auto flush = [&]() -> int {
         if (cnt == 0) return 0;
-        LV<int> lit, ml, off, len, opos;
-        LV<bool> act;
+        LV<int> lit, ml, lsrc;
         FOR_LANES(l) {
-            act[l] = l < cnt;
-            lit[l] = act[l] ? (TA[l] & 0xFFFF) : 0;
-            ml[l] = act[l] ? (TA[l] >> 16) : 0;
-            off[l] = act[l] ? TB[l] : 1;
-            len[l] = lit[l] + ml[l];
+            lit[l] = TA[l] & 0xFFFF;
+            ml[l] = TA[l] >> 16;
+            lsrc[l] = TP[l] + 1 + (lit[l] >= 15 ? 1 : 0);
         }
-        int acc;
-        wave_exscan(len, opos, acc);
-        if (acc > oend - op) {                             // cut at the first token that does not fit: the scalar path meets it next
-            const int room = oend - op;
-            LV<bool> over;
-            FOR_LANES(l) { over[l] = act[l] & (opos[l] + len[l] > room); }
-            const int f = ctz64(ballot(over));
-            ip = readlane(TP, f);
-            cnt = f;
-            acc = readlane(opos, f);
-            force_scalar = true;
-            FOR_LANES(l) { act[l] = l < cnt; if (!act[l]) { lit[l] = 0; ml[l] = 0; off[l] = 1; } }
-            if (cnt == 0) return 0;
-        }
-        LV<int> P, D, S;
-        LV<bool> badv;
-        FOR_LANES(l) {
-            P[l] = act[l] ? op + opos[l] : 0x7FFFFFFF;     // (lanes behind the batch: beyond every position the searches ask for)
-            D[l] = op + opos[l] + lit[l];
-            S[l] = D[l] - off[l];
-            badv[l] = act[l] & (S[l] < base);
-        }
-        if (ballot(badv)) return ERR_DATA;
-        // ---- literals: the bytes behind the token byte (and its length byte, from 15 literals on).  Every lane fetches the first 16
-        // bytes of its run; runs longer than that are finished one after the other, in token order, by the whole wave; then every
-        // lane stores its first bytes.  (The output of a token may lie on the compressed bytes of the tokens in front of it -- never on
-        // those behind: all first pieces are in registers before anything is written, and the long runs go in order.)
-        {
-            LV<u128> v;
-            LV<int> lsrc;
-            LV<bool> longer;
-            FOR_LANES(l) {
-                lsrc[l] = TP[l] + 1 + (lit[l] >= 15 ? 1 : 0);
-                longer[l] = act[l] & (lit[l] > 16);
-                const int sa = imin(lsrc[l], clampmax);
-                const int a = sa & ~3;
-                const uint32_t sh = (uint32_t)sa & 3u;
-                const uint32_t q0 = *reinterpret_cast<const uint32_t*>(lds + imin(a, clampmax));
-                const uint32_t q1 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 4, clampmax));
-                const uint32_t q2 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 8, clampmax));
-                const uint32_t q3 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 12, clampmax));
-                const uint32_t q4 = *reinterpret_cast<const uint32_t*>(lds + imin(a + 16, clampmax));
-                v[l].x = alignbyte(q1, q0, sh); v[l].y = alignbyte(q2, q1, sh); v[l].z = alignbyte(q3, q2, sh); v[l].w = alignbyte(q4, q3, sh);
-            }
-            uint64_t todo = ballot(longer);
-            while (todo) {
-                const int t = ctz64(todo);
-                todo &= todo - 1;
-                lds_copy_bytes(lds, readlane(P, t) + 16, readlane(lsrc, t) + 16, readlane(lit, t) - 16);
-            }
-            FOR_LANES_W(l) {
-                const int nlit = act[l] ? imin(lit[l], 16) : 0;
-                uint8_t* d = lds + (act[l] ? P[l] : base);
-                const uint32_t w4[4] = {v[l].x, v[l].y, v[l].z, v[l].w};
-                CIMG_UNROLL
-                for (int j = 0; j < 4; j++) { if (nlit >= 4 * j + 4) lds_st32u(d + 4 * j, w4[j]); }
-                const int t = nlit & ~3;
-                const uint32_t last = t < 16 ? w4[(t >> 2) & 3] : 0;
-                CIMG_UNROLL
-                for (int k = 0; k < 3; k++) { if (nlit > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
-            }
-        }
-        // ---- matches.  Which batch tokens does a match's source touch?  need = the bytes it reads before writing (a fill reads
-        // one, a match that overlaps itself its first `offset`); cntP(x) = tokens whose output starts at or below x.
-        LV<bool> hasm, ovl;
-        LV<int> lo_i, hi_i;
-        {
-            LV<int> ca, cb, xa, xb;
-            FOR_LANES(l) {
-                hasm[l] = act[l] & (ml[l] > 0);
-                ovl[l] = hasm[l] & (((off[l] < ml[l]) & (off[l] != 1)) | (ml[l] > 64));      // copied by the whole wave, in its turn
-                const int need = off[l] == 1 ? 1 : (off[l] < ml[l] ? off[l] : ml[l]);
-                xa[l] = S[l]; xb[l] = S[l] + need - 1;
-                ca[l] = 0; cb[l] = 0;
-            }
-            CIMG_UNROLL
-            for (int k = 5; k >= 0; --k) {
-                LV<int> ta, tb, pa, pb;
-                FOR_LANES(l) { ta[l] = ca[l] + (1 << k) - 1; tb[l] = cb[l] + (1 << k) - 1; }     // index of the (count + 2^k)-th token
-                lane_gather(P, ta, pa);
-                lane_gather(P, tb, pb);
-                FOR_LANES(l) {
-                    if (ta[l] < 64 && pa[l] <= xa[l]) ca[l] += 1 << k;
-                    if (tb[l] < 64 && pb[l] <= xb[l]) cb[l] += 1 << k;
-                }
-            }
-            // tokens ja = ca - 1 .. jb = cb - 1 produce the source bytes (ca == 0: the source begins in front of the batch); the match
-            // waits for the MATCHES of those below itself (their literals are in place; its own literals too)
-            FOR_LANES(l) {
-                lo_i[l] = ca[l] > 0 ? ca[l] - 1 : 0;
-                hi_i[l] = imin(cb[l] - 1, l - 1);
-            }
-        }
-        uint64_t done = ~ballot(hasm);
-#ifdef CIMG_EMULATE
-        g_emu_d2[2]++;
-#endif
-        for (int round = 0; round < 128 && ~done; ++round) {
-            LV<bool> ready;
-            FOR_LANES(l) {
-                const uint64_t upto = hi_i[l] >= 63 ? ~0ull : ((1ull << (hi_i[l] + 1)) - 1);
-                const uint64_t from = lo_i[l] >= 64 ? 0ull : (~0ull << lo_i[l]);
-                const uint64_t deps = hi_i[l] >= lo_i[l] ? (upto & from) : 0ull;
-                ready[l] = !((done >> l) & 1) & ((deps & ~done) == 0) & !ovl[l];
-            }
-            const uint64_t rmask = ballot(ready);
-            // (one or two ready matches: the wave-wide copy of the FIRST pending match below is cheaper than the dense-descriptor
-            // machinery -- that match is always executable: everything it depends on lies below it and is done)
-#ifdef CIMG_EMULATE
-            g_emu_d2[3]++; if (popc64(rmask) >= 3) g_emu_d2[4] += popc64(rmask); else g_emu_d2[5]++;
-#endif
-            if (popc64(rmask) >= 3) {
-                const int R = popc64(rmask);
-                LV<int> rank, d0, d1, D0, D1;
-                FOR_LANES(l) {
-                    rank[l] = ready[l] ? lane_rank(rmask, l) : 63;   // (a batch has at most 63 tokens: slot 63 is nobody's)
-                    d0[l] = D[l] | (ml[l] << 18);
-                    d1[l] = S[l] | (off[l] == 1 ? 1 << 18 : 0);
-                }
-                lane_scatter(d0, rank, D0);
-                lane_scatter(d1, rank, D1);
-                for (int g = 0; g < R; g += 16) {
-                    LV<int> who, e0, e1;
-                    FOR_LANES(l) { who[l] = g + (l >> 2); }
-                    lane_gather(D0, who, e0);
-                    lane_gather(D1, who, e1);
-                    LV<u128> w;
-                    FOR_LANES(l) {
-                        const bool on = who[l] < R;
-                        const bool f = (e1[l] >> 18) & 1;
-                        const int sa = on ? (e1[l] & 0x3FFFF) + (f ? 0 : (l & 3) * 16) : base;
-                        const int a = sa & ~3;
-                        const uint32_t sh = (uint32_t)sa & 3u;
-                        const uint32_t q0 = *reinterpret_cast<const uint32_t*>(lds + a);
-                        const uint32_t q1 = *reinterpret_cast<const uint32_t*>(lds + a + 4);
-                        const uint32_t q2 = *reinterpret_cast<const uint32_t*>(lds + a + 8);
-                        const uint32_t q3 = *reinterpret_cast<const uint32_t*>(lds + a + 12);
-                        const uint32_t q4 = *reinterpret_cast<const uint32_t*>(lds + a + 16);
-                        const uint32_t x0 = alignbyte(q1, q0, sh);
-                        const uint32_t fb = (x0 & 0xFF) * 0x01010101u;
-                        w[l].x = f ? fb : x0;
-                        w[l].y = f ? fb : alignbyte(q2, q1, sh);
-                        w[l].z = f ? fb : alignbyte(q3, q2, sh);
-                        w[l].w = f ? fb : alignbyte(q4, q3, sh);
-                    }
-                    FOR_LANES_W(l) {
-                        const int rem = who[l] < R ? ((e0[l] >> 18) & 0x7F) - (l & 3) * 16 : 0;
-                        uint8_t* d = lds + (e0[l] & 0x3FFFF) + (l & 3) * 16;
-                        const uint32_t v4[4] = {w[l].x, w[l].y, w[l].z, w[l].w};
-                        CIMG_UNROLL
-                        for (int j = 0; j < 4; j++) { if (rem >= 4 * j + 4) lds_st32u(d + 4 * j, v4[j]); }
-                        const int t = rem > 0 ? (rem > 16 ? 16 : rem) & ~3 : 0;
-                        const uint32_t last = t < 16 ? v4[(t >> 2) & 3] : 0;
-                        CIMG_UNROLL
-                        for (int k = 0; k < 3; k++) { if (rem > t + k && t + k < 16) d[t + k] = (uint8_t)(last >> (8 * k)); }
-                    }
-                }
-                done |= rmask;
-            } else {
-                // the first match not done: everything it depends on lies below it and is done
-                const int t = ctz64(~done);
-                const int dst = readlane(D, t), src = readlane(S, t), mlen = readlane(ml, t);
-                const int offset = dst - src;
-                if (mlen <= 64) {
-                    LV<uint32_t> mv;
-                    if (offset >= mlen) { FOR_LANES(l) { mv[l] = lds[src + (l < mlen ? l : 0)]; } }
-                    else if (offset == 1) { FOR_LANES(l) { mv[l] = lds[src]; } }
-                    else {
-                        const float inv = fast_rcp((float)offset);
-                        FOR_LANES(l) { mv[l] = lds[src + small_mod(l < mlen ? l : 0, offset, inv)]; }
-                    }
-                    FOR_LANES_W(l) { if (l < mlen) lds[dst + l] = (uint8_t)mv[l]; }
-                } else {
-                    lds_copy_match(lds, dst, src, mlen);
-                }
-                done |= 1ull << t;
-            }
-        }
-        op += acc;
+        int cut = -1;
+        const int rc = lz_batch_execute<uint8_t*>(lds, base, oend, clampmax, op, cnt, lit, ml, TB, lsrc, cut);
+        if (cut >= 0) { ip = readlane(TP, cut); force_scalar = true; }
         cnt = 0;
-        return 0;
+        return rc;
     };
 
     for (;;) {
@@ -1185,7 +1236,7 @@ struct DecodeBlock {
             return;
         }
         const int fmt = flags >> 5;                                  // 0 blosclz, 1 lz4 / lz4hc
-        if (fmt != 0 && fmt != 1) { fail(fmt == 4 ? STATUS_ZSTD_PENDING : ERR_CODEC_SUPPORT); return; }   // zstd: cimg_decode_zstd's
+        if (fmt != 0 && fmt != 1) { fail(fmt == 4 ? ((flags & FLAG_DONT_SPLIT) || ts <= 1 ? STATUS_ZSTD_PENDING : STATUS_ZSTD_PENDING_SPLIT) : ERR_CODEC_SUPPORT); return; }   // zstd: cimg_decode_zstd's
         // filter pipeline: exactly one of {none, shuffle, bitshuffle}, in the last slot
         filter = (int)((f1 >> 8) & 0xFF);
         if (f0 != 0 || (f1 & 0xFF) != 0) { fail(ERR_CODEC_SUPPORT); return; }

@@ -91,13 +91,27 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2
     w.run((int)blockIdx.x, (int)gridDim.x);
 }
 
-// blocks of zstd-coded chunks, one wave per block: the slow path that keeps chunks written with enums::codec::zstd readable
-// (zstd_kernel.h); launched only behind a batch in which cimg_decode_blocks met such a chunk
+// blocks of zstd-coded chunks: the slow path that keeps chunks written with enums::codec::zstd readable (zstd_kernel.h); launched
+// only behind a batch in which cimg_decode_blocks met such a chunk.  One wave per block for chunks of one stream per block, two
+// waves per block -- each with tables of its own, taking streams from a counter -- for split ones.
 extern "C" __global__ __launch_bounds__(64) void cimg_decode_zstd(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    DecodeZstdBlock blk(a, lds, (int)blockIdx.x);
-    blk.run();
+    DecodeZstdBlock blk(a, lds, (int)blockIdx.x, 1);
+    blk.init();
+    blk.phase_a(0);
+    blk.phase_b(0);
+}
+extern "C" __global__ __launch_bounds__(128) void cimg_decode_zstd_split(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    DecodeZstdBlock blk(a, lds, (int)blockIdx.x, 2);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave == 0) blk.init();
+    __syncthreads();
+    blk.phase_a(wave);
+    __syncthreads();
+    blk.phase_b(wave);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cimg_decode_blocks(DecodeArgs a)
@@ -212,7 +226,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    int max_dyn_lds[6] = {0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd)
+    int max_dyn_lds[7] = {0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -980,20 +994,34 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     // zstd chunks (codec format 4) came back with the internal word STATUS_ZSTD_PENDING: they have a decoder of their own -- one
     // wave per block, only ever launched here.  Exactly those words are cleared (a chunk of this engine's codecs with a filter
     // pipeline nobody reads keeps its ERR_CODEC_SUPPORT), cimg_decode_zstd goes over the batch, and the words are read once more.
-    std::vector<int> unread_chunks;
-    for (int i = 0; i < nchunks; i++) if (st[i] == STATUS_ZSTD_PENDING) { st[i] = 0; unread_chunks.push_back(i); }
-    if (!unread_chunks.empty()) {
+    std::vector<int> unread_chunks[2];                      // [1]: split chunks
+    for (int i = 0; i < nchunks; i++) if (st[i] == STATUS_ZSTD_PENDING || st[i] == STATUS_ZSTD_PENDING_SPLIT) { unread_chunks[st[i] == STATUS_ZSTD_PENDING_SPLIT].push_back(i); st[i] = 0; }
+    bool launched = false;
+    // (blocks so large that two sets of tables do not fit a workgroup's LDS beside them: the one-wave launch reads every kind)
+    const bool two_waves = !unread_chunks[1].empty() && zstd_kernel_lds_bytes(f.max_blocksize, 2) <= e->lds_per_wg;
+    if (!two_waves) { unread_chunks[0].insert(unread_chunks[0].end(), unread_chunks[1].begin(), unread_chunks[1].end()); unread_chunks[1].clear(); }
+    for (int kind = 0; kind < 2; kind++) {
+        if (unread_chunks[kind].empty()) continue;
         DecodeArgs za = da;
-        za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize);
+        const int waves = kind ? 2 : 1;
+        za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize, waves);
         za.dbg = nullptr; za.done = nullptr; za.skipped = nullptr;
+        za.tune = two_waves ? 1 : 0;                        // 1: each launch reads the chunks of its own kind only
         if (za.lds_bytes > e->lds_per_wg) {
-            for (int i : unread_chunks) st[i] = ERR_CODEC_SUPPORT;                        // blocks too large for one workgroup's LDS
+            for (int i : unread_chunks[kind]) st[i] = ERR_CODEC_SUPPORT;                  // blocks too large for one workgroup's LDS
+        } else if (kind) {
+            if ((rc = e->allow_lds(cimg_decode_zstd_split, 6, za.lds_bytes))) return rc;
+            if ((rc = e->launch(CIMG_K_DECODE_ZSTD, cimg_decode_zstd_split, za, plan.total_blocks, 128, za.lds_bytes))) return rc;
+            launched = true;
         } else {
             if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
             if ((rc = e->launch(CIMG_K_DECODE_ZSTD, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;
-            if ((rc = cimg_engine_synchronize(e))) return rc;
-            e->zstd_batches++;
+            launched = true;
         }
+    }
+    if (launched) {
+        if ((rc = cimg_engine_synchronize(e))) return rc;
+        e->zstd_batches++;
     }
     int first = 0;
     for (int i = 0; i < nchunks; i++) {

@@ -118,6 +118,7 @@ inline void fence_release() {}
 inline void fence_acquire() {}
 inline uint32_t atomic_add_agent(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t atomic_load_agent(const uint32_t* p) { return *p; }
+inline uint32_t atomic_add_workgroup(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void atomic_store_agent(uint32_t* p, uint32_t v) { *p = v; }
 inline uint32_t atomic_exchange_agent(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = v; return o; }
 inline void wave_nap() {}
@@ -270,6 +271,8 @@ CIMG_DEV void fence_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"
 #endif
 CIMG_DEV uint32_t atomic_add_agent(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CIMG_DEV uint32_t atomic_load_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a counter in LDS that the waves of one workgroup share (zstd_kernel.h: which stream of the block next)
+CIMG_DEV uint32_t atomic_add_workgroup(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 CIMG_DEV void atomic_store_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 CIMG_DEV uint32_t atomic_exchange_agent(uint32_t* p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every store this wave issued so far is acknowledged (write-through stores: at the memory side)

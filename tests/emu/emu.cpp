@@ -20,7 +20,8 @@
 #define EMU_LDS_SLACK 64
 #endif
 
-namespace cimg { long g_emu_zx_batches = 0, g_emu_zx_rounds = 0, g_emu_zx_par = 0, g_emu_zx_serial = 0, g_emu_zx_longlit = 0; }
+namespace cimg {
+int g_emu_zstd_take = 1 << 30; long g_emu_zx_batches = 0, g_emu_zx_rounds = 0, g_emu_zx_par = 0, g_emu_zx_serial = 0, g_emu_zx_longlit = 0; }
 namespace cimg { long g_emu_d2[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
 namespace cimg { long g_emu_dec_par = 0, g_emu_dec_serial = 0, g_emu_dec_batches = 0; int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
@@ -167,19 +168,41 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         for (int w = 0; w < 4; w++) ws[w]->phase_b(w);
     }
     // as the engine does (decompress_finish): chunks nobody read yet go to the zstd kernel
-    bool unread = false;
-    for (int i = 0; i < nchunks; i++) if (status[i] == STATUS_ZSTD_PENDING) { status[i] = 0; unread = true; }
-    if (unread) {
+    // (one wave per block for chunks of one stream per block, two waves for split ones; each launch reads its own kind only)
+    bool unread[2] = {false, false};
+    for (int i = 0; i < nchunks; i++) if (status[i] == STATUS_ZSTD_PENDING || status[i] == STATUS_ZSTD_PENDING_SPLIT) { unread[status[i] == STATUS_ZSTD_PENDING_SPLIT] = true; status[i] = 0; }
+    int max_bs = 0;
+    for (const ChunkDesc& d : plan.descs) max_bs = d.blocksize > max_bs ? d.blocksize : max_bs;
+    const bool two_waves = unread[1] && zstd_kernel_lds_bytes(max_bs, 2) <= 163840;       // (engine.hip: decompress_finish)
+    if (!two_waves) { unread[0] = unread[0] || unread[1]; unread[1] = false; }
+    for (int kind = 0; kind < 2; kind++) {
+        if (!unread[kind]) continue;
+        const int nw = kind ? 2 : 1;
         DecodeArgs za = da;
-        int max_bs = 0;
-        for (const ChunkDesc& d : plan.descs) max_bs = d.blocksize > max_bs ? d.blocksize : max_bs;
-        za.lds_bytes = zstd_kernel_lds_bytes(max_bs);
+        za.lds_bytes = zstd_kernel_lds_bytes(max_bs, nw);
         za.done = nullptr;
+        za.tune = two_waves ? 1 : 0;
         std::vector<uint8_t> zl((size_t)za.lds_bytes + EMU_LDS_SLACK);
         for (int b = 0; b < plan.total_blocks; b++) {
             memset(zl.data(), 0xCD, zl.size());
-            DecodeZstdBlock blk(za, zl.data(), b);
-            blk.run();
+            DecodeZstdBlock w0(za, zl.data(), b, nw), w1(za, zl.data(), b, nw);
+            DecodeZstdBlock* ws[2] = {&w0, &w1};
+            w0.init();
+            // the waves of a block run one after the other here.  Every other block whoever goes first gets every stream from the
+            // counter; in the blocks between, a wave comes back after ONE stream and the other one goes on (each call walks the
+            // stream headers from the block's first again, over the streams the other wave took)
+            const int first = nw > 1 ? (b & 1) : 0;
+            g_emu_zstd_take = (nw > 1 && (b & 2)) ? 1 : (1 << 30);
+            bool active[2] = {true, nw > 1};
+            for (int it = 0; it < 1024 && (active[0] || active[1]); ++it) {
+                const int k = (first + it) % nw;
+                if (!active[k]) continue;
+                ws[k]->phase_a(k);
+                const uint32_t* ctl = ws[k]->ctl();
+                if ((int)ctl[2 + 2 * k] != ZSTD_BLOCK_FINE || g_emu_zstd_take > 1024 || (int)ctl[0] > ws[k]->ns) active[k] = false;
+            }
+            g_emu_zstd_take = 1 << 30;
+            for (int k = 0; k < nw; k++) ws[k]->phase_b(k);
         }
     }
     return 0;

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import _emu as E
+import _oracle as O
 from cimg import synth
 
 
@@ -64,6 +65,47 @@ def test_blosc2_zstd_chunks_decode_through_the_kernels(kat):
         rc, status, out = E.decompress_batch([chunk.tobytes()], [src.size], [bs])
         assert rc == 0 and status == [0], (name, rc, status)
         assert out[0].tobytes() == src.tobytes(), name
+
+
+def test_split_and_unsplit_zstd_chunks_in_one_batch(kat):
+    """Split chunks go to the two-waves-per-block launch, chunks of one stream per block to the one-wave launch (engine.hip:
+    decompress_finish; each launch reads its own kind only): one batch with both, and LZ4 chunks between them."""
+    names = ["tiled_u16_split", "tiled_f16_unsplit", "natural_f32_split", "u8_small_blocks", "mixed_u16", "natural_f32_split"]
+    chunks = [kat["chunk|" + n].tobytes() for n in names]
+    srcs = [kat["cin|" + n] for n in names]
+    bss = [int(np.frombuffer(c[8:12], "<i4")[0]) for c in chunks]
+    lz4 = O.compress(O.cparams(2, clevel=5, blocksize=32768), srcs[0])[1]
+    chunks.insert(2, lz4); srcs.insert(2, srcs[0]); bss.insert(2, 32768)
+    rc, status, out = E.decompress_batch(chunks, [s.size for s in srcs], bss)
+    assert rc == 0 and status == [0] * len(chunks), (rc, status)
+    for o, s_, n in zip(out, srcs, range(len(srcs))):
+        assert o.tobytes() == s_.tobytes(), n
+
+
+def test_the_lowest_damaged_stream_of_a_split_block_is_the_one_reported(kat):
+    """Two waves share the streams of a block; what the chunk reports is what decoding the streams in order reports: damage in a
+    LATER stream only (a stream header that points outside the chunk = ERR_READ_BUFFER) against damage in the first frame (ERR_DATA
+    class) AND the later header."""
+    good = kat["chunk|natural_f32_split"]
+    src = kat["cin|natural_f32_split"]
+    bs = int(np.frombuffer(good[8:12].tobytes(), "<i4")[0])
+    raw = good.tobytes()
+    nblocks = -(-src.size // bs)
+    b0 = int(np.frombuffer(raw[32:36], "<i4")[0])
+    cs0 = int(np.frombuffer(raw[b0:b0 + 4], "<i4")[0])
+    assert 0 < cs0 < bs // 4
+    late = good.copy()
+    late[b0 + 4 + cs0:b0 + 8 + cs0] = np.frombuffer(np.int32(1 << 24).tobytes(), np.uint8)      # stream 1's size word
+    rc, st_late, _ = E.decompress_batch([late.tobytes()], [src.size], [bs])
+    both = late.copy()
+    both[b0 + 4 + 6:b0 + 4 + 40] ^= 0x5A                                                          # inside stream 0's frame
+    rc, st_both, _ = E.decompress_batch([both.tobytes()], [src.size], [bs])
+    first = good.copy()
+    first[b0 + 4 + 6:b0 + 4 + 40] ^= 0x5A
+    rc, st_first, _ = E.decompress_batch([first.tobytes()], [src.size], [bs])
+    assert st_late[0] < 0 and st_first[0] < 0
+    assert st_both == st_first, (st_both, st_first, st_late)
+    assert nblocks >= 1
 
 
 def test_a_damaged_zstd_chunk_reports_an_error_and_leaves_its_neighbours_alone(kat):
