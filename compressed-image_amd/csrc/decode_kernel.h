@@ -55,6 +55,12 @@ struct DecodeArgs {
     // decode_lean_kernel.h: run) -- bits 0-7: the younger wave of a SIMD starts n x 64 cycles late; bit 8: from its second block on
     // the younger wave runs at raised priority
     int32_t tune;
+    // the zstd read path's two launches (zstd_walk_kernel.h): block blk_first + k has slot k of `zplan`; zcap bytes of records and of
+    // literals a slot; zarea = the plane area of the replay launch (a block larger than that is nobody's).  cimg_decode_zstd with
+    // zplan set reads exactly the blocks whose plan was marked as not fitting.
+    uint8_t* zplan;
+    int64_t zplan_stride;
+    int32_t zcap, zarea;
 };
 
 CIMG_HD int round16(int x) { return (x + 15) & ~15; }

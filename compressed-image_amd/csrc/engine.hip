@@ -16,6 +16,7 @@
 #include "assemble_kernel.h"
 #include "deinterleave_kernel.h"
 #include "zstd_kernel.h"
+#include "zstd_walk_kernel.h"
 #include "../../include/cimg_hip.h"
 
 using namespace cimg;
@@ -97,15 +98,29 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2
 extern "C" __global__ __launch_bounds__(64) void cimg_decode_zstd(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    DecodeZstdBlock blk(a, lds, (int)blockIdx.x, 1);
+    DecodeZstdBlock blk(a, lds, a.blk_first + (int)blockIdx.x, 1);
     blk.init();
     blk.phase_a(0);
     blk.phase_b(0);
 }
+// the zstd read path as two launches (zstd_walk_kernel.h): what the frames say goes to a plan in global memory (entropy decoding,
+// eight waves a CU), then the plans are replayed into the blocks (four waves a CU, the output in LDS)
+extern "C" __global__ __launch_bounds__(64) void cimg_zstd_walk(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    ZstdWalkBlock blk(a, lds, a.blk_first + (int)blockIdx.x);
+    blk.run();
+}
+extern "C" __global__ __launch_bounds__(64) void cimg_zstd_replay(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    ZstdReplayBlock blk(a, lds, a.blk_first + (int)blockIdx.x);
+    blk.run();
+}
 extern "C" __global__ __launch_bounds__(128) void cimg_decode_zstd_split(DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    DecodeZstdBlock blk(a, lds, (int)blockIdx.x, 2);
+    DecodeZstdBlock blk(a, lds, a.blk_first + (int)blockIdx.x, 2);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave == 0) blk.init();
     __syncthreads();
@@ -207,6 +222,12 @@ struct cimg_engine {
     int lean_tune = getenv("CIMG_LEAN_TUNE") ? atoi(getenv("CIMG_LEAN_TUNE")) : (0x10000 | 0x100 | (3 << 9) | 16);
     int lean_hold = getenv("CIMG_NO_LEAN") ? (1 << 30) : 0;   // batches for which the lean launch is skipped
     int64_t zstd_batches = 0;           // decode batches that needed cimg_decode_zstd
+    int64_t zstd_blocks_refused = 0;    // blocks whose plan did not fit its slot (decoded by cimg_decode_zstd behind the two launches)
+    int zstd_fused = getenv("CIMG_ZSTD_FUSED") ? atoi(getenv("CIMG_ZSTD_FUSED")) : 0;          // 1: cimg_decode_zstd only (no walk / replay launches)
+    int zstd_plan_cap = getenv("CIMG_ZSTD_PLAN_CAP") ? atoi(getenv("CIMG_ZSTD_PLAN_CAP")) : 0;   // diagnostic: bytes of records / literals a plan may take (0: the block area)
+    int64_t zstd_plan_bytes = getenv("CIMG_ZSTD_PLAN_MIB") ? atoll(getenv("CIMG_ZSTD_PLAN_MIB")) << 20 : 2048ll << 20;   // plans of one pair of launches (larger batches: in groups)
+    int zstd_walk_stage = getenv("CIMG_ZSTD_WALK_STAGE") ? atoi(getenv("CIMG_ZSTD_WALK_STAGE")) : 2048;   // bytes of LDS through which a walker reads a frame's sections (measured on 128 MiB of level-22 float32: 8192 = 8 waves a CU 2.51 ms, 4096 = 10 waves 2.45, 2048 = 11 waves 2.28 -- a section that does not fit is read where it lies)
+    DevBuf zplan;
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
     uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over BEYOND the leftover blocks its geometry announced (1: unknown yet -> general kernel enqueued up front)
     int num_cus = 256;
@@ -226,7 +247,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    int max_dyn_lds[7] = {0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
+    int max_dyn_lds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -391,6 +412,9 @@ const char* cimg_kernel_name(int k)
     case CIMG_K_DEINTERLEAVE: return "cimg_deinterleave";
     case CIMG_K_DECODE_ZSTD: return "cimg_decode_zstd";
     case CIMG_K_ENCODE_ZSTD: return "cimg_encode_streams_zstd";
+    case CIMG_K_ZSTD_WALK: return "cimg_zstd_walk";
+    case CIMG_K_ZSTD_REPLAY: return "cimg_zstd_replay";
+    case CIMG_K_ZSTD_FUSED: return "cimg_decode_zstd_fused";
     default: return "?";
     }
 }
@@ -461,7 +485,7 @@ void cimg_engine_destroy(cimg_engine* e)
     (void)hipStreamSynchronize(e->stream);
     e->drain_timing();
     for (EventPair& ev : e->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item, &e->qheads, &e->zstd_seq, &e->zstd_tables})
+    for (DevBuf* b : {&e->descs_enc, &e->descs_dec, &e->recs, &e->layout, &e->scratch, &e->stage_raw, &e->stage_comp, &e->stage_il, &e->dbg, &e->queue, &e->done, &e->sync, &e->next_item, &e->qheads, &e->zstd_seq, &e->zstd_tables, &e->zplan})
         if (b->p) (void)hipFree(b->p);
     for (PinBuf* b : {&e->h_descs, &e->h_descs_dec, &e->h_out, &e->h_dec})
         if (b->p) (void)hipHostFree(b->p);
@@ -997,28 +1021,82 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
     std::vector<int> unread_chunks[2];                      // [1]: split chunks
     for (int i = 0; i < nchunks; i++) if (st[i] == STATUS_ZSTD_PENDING || st[i] == STATUS_ZSTD_PENDING_SPLIT) { unread_chunks[st[i] == STATUS_ZSTD_PENDING_SPLIT].push_back(i); st[i] = 0; }
     bool launched = false;
-    // (blocks so large that two sets of tables do not fit a workgroup's LDS beside them: the one-wave launch reads every kind)
-    const bool two_waves = !unread_chunks[1].empty() && zstd_kernel_lds_bytes(f.max_blocksize, 2) <= e->lds_per_wg;
-    if (!two_waves) { unread_chunks[0].insert(unread_chunks[0].end(), unread_chunks[1].begin(), unread_chunks[1].end()); unread_chunks[1].clear(); }
-    for (int kind = 0; kind < 2; kind++) {
-        if (unread_chunks[kind].empty()) continue;
-        DecodeArgs za = da;
-        const int waves = kind ? 2 : 1;
-        za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize, waves);
-        za.dbg = nullptr; za.done = nullptr; za.skipped = nullptr;
-        za.tune = two_waves ? 1 : 0;                        // 1: each launch reads the chunks of its own kind only
-        if (za.lds_bytes > e->lds_per_wg) {
-            for (int i : unread_chunks[kind]) st[i] = ERR_CODEC_SUPPORT;                  // blocks too large for one workgroup's LDS
-        } else if (kind) {
-            if ((rc = e->allow_lds(cimg_decode_zstd_split, 6, za.lds_bytes))) return rc;
-            if ((rc = e->launch(CIMG_K_DECODE_ZSTD, cimg_decode_zstd_split, za, plan.total_blocks, 128, za.lds_bytes))) return rc;
-            launched = true;
-        } else {
-            if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
-            if ((rc = e->launch(CIMG_K_DECODE_ZSTD, cimg_decode_zstd, za, plan.total_blocks, 64, za.lds_bytes))) return rc;
-            launched = true;
+    const bool any_zstd = !unread_chunks[0].empty() || !unread_chunks[1].empty();
+    // (one event pair around whatever the read path launches: CIMG_K_DECODE_ZSTD is the time of the whole path)
+    EventPair zev{};
+    const bool ztimed = any_zstd && e->timing;
+    if (ztimed) { zev = e->get_events(); (void)hipEventRecord(zev.a, e->stream); }
+    // The fused kernels (one launch, output + stage + tables in LDS together): everything when CIMG_ZSTD_FUSED=1, and the blocks the
+    // walk refused.  (Blocks so large that two sets of tables do not fit a workgroup's LDS beside them: the one-wave launch reads
+    // every kind.)  only_refused: DecodeArgs::zplan is set and the kernels read the blocks whose plan says ZPLAN_FALLBACK.
+    auto fused = [&](const DecodeArgs& base, int blk_first, int nblocks) -> int {
+        const bool two_waves = !unread_chunks[1].empty() && zstd_kernel_lds_bytes(f.max_blocksize, 2) <= e->lds_per_wg;
+        for (int kind = 0; kind < 2; kind++) {
+            const bool has = kind ? (two_waves && !unread_chunks[1].empty()) : (!unread_chunks[0].empty() || (!two_waves && !unread_chunks[1].empty()));
+            if (!has) continue;
+            DecodeArgs za = base;
+            const int waves = kind ? 2 : 1;
+            za.lds_bytes = zstd_kernel_lds_bytes(f.max_blocksize, waves);
+            za.blk_first = blk_first;
+            za.tune = two_waves ? 1 : 0;                        // 1: each launch reads the chunks of its own kind only
+            if (za.lds_bytes > e->lds_per_wg) {
+                // blocks too large for one workgroup's LDS (behind a walk that refused blocks nobody knows whose they are: the call fails)
+                if (base.zplan) return e->fail(ERR_CODEC_SUPPORT, "zstd blocks of %d bytes: a plan did not fit and the blocks are too large for cimg_decode_zstd", (int)f.max_blocksize);
+                for (int k2 = 0; k2 < 2; k2++) for (int i : unread_chunks[k2]) if (kind == k2 || !two_waves) st[i] = ERR_CODEC_SUPPORT;
+            } else if (kind) {
+                if ((rc = e->allow_lds(cimg_decode_zstd_split, 6, za.lds_bytes))) return rc;
+                if ((rc = e->launch(CIMG_K_ZSTD_FUSED, cimg_decode_zstd_split, za, nblocks, 128, za.lds_bytes))) return rc;
+                launched = true;
+            } else {
+                if ((rc = e->allow_lds(cimg_decode_zstd, 5, za.lds_bytes))) return rc;
+                if ((rc = e->launch(CIMG_K_ZSTD_FUSED, cimg_decode_zstd, za, nblocks, 64, za.lds_bytes))) return rc;
+                launched = true;
+            }
         }
-    }
+        return 0;
+    };
+    auto read_path = [&]() -> int {
+        if (!any_zstd) return 0;
+        DecodeArgs zb = da;
+        zb.dbg = nullptr; zb.done = nullptr; zb.skipped = nullptr; zb.zplan = nullptr;
+        const int replay_lds = zstd_replay_lds_bytes(f.max_blocksize);
+        if (e->zstd_fused || replay_lds > e->lds_per_wg) {
+            if ((rc = fused(zb, 0, plan.total_blocks))) return rc;
+        } else {
+            const int area = zstd_kernel_area(f.max_blocksize);
+            const int cap = e->zstd_plan_cap > 0 ? e->zstd_plan_cap : area;
+            const int64_t stride = zstd_plan_stride(cap);
+            const int group = (int)std::max<int64_t>(1, std::min<int64_t>(plan.total_blocks, e->zstd_plan_bytes / stride));
+            if ((rc = e->reserve(e->zplan, (size_t)group * (size_t)stride))) return rc;
+            volatile uint32_t* refused = skipped_host;           // (the lean launch's words have been read: the first one counts refused plans now)
+            zb.skipped = (uint32_t*)((uint8_t*)da.status + ((f.st_bytes + 15) & ~(size_t)15));
+            zb.zplan = (uint8_t*)e->zplan.p; zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area;
+            if ((rc = e->allow_lds(cimg_zstd_walk, 7, zstd_walk_lds_bytes(e->zstd_walk_stage)))) return rc;
+            if ((rc = e->allow_lds(cimg_zstd_replay, 8, replay_lds))) return rc;
+            for (int g0 = 0; g0 < plan.total_blocks; g0 += group) {
+                const int nb = std::min(group, plan.total_blocks - g0);
+                *refused = 0;
+                DecodeArgs wa = zb;
+                wa.blk_first = g0; wa.lds_bytes = zstd_walk_lds_bytes(e->zstd_walk_stage);
+                if ((rc = e->launch(CIMG_K_ZSTD_WALK, cimg_zstd_walk, wa, nb, 64, wa.lds_bytes))) return rc;
+                DecodeArgs ra = zb;
+                ra.blk_first = g0; ra.lds_bytes = replay_lds;
+                if ((rc = e->launch(CIMG_K_ZSTD_REPLAY, cimg_zstd_replay, ra, nb, 64, ra.lds_bytes))) return rc;
+                launched = true;
+                if ((rc = cimg_engine_synchronize(e))) return rc;
+                if (*refused) {
+                    e->zstd_blocks_refused += *refused;
+                    if (e->verbose) fprintf(stderr, "[cimg] zstd: %u of %d plans did not fit their slots (cimg_decode_zstd reads those blocks)\n", (unsigned)*refused, nb);
+                    if ((rc = fused(zb, g0, nb))) return rc;
+                    if ((rc = cimg_engine_synchronize(e))) return rc;
+                }
+            }
+        }
+        return 0;
+    };
+    rc = read_path();
+    if (rc) return rc;
+    if (ztimed) { (void)hipEventRecord(zev.b, e->stream); e->pending[CIMG_K_DECODE_ZSTD].push_back(zev); }
     if (launched) {
         if ((rc = cimg_engine_synchronize(e))) return rc;
         e->zstd_batches++;

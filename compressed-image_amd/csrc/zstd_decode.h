@@ -25,9 +25,27 @@ enum : int { ZSTD_HUF_LOG_MAX = 11, ZSTD_FSE_LOG_MAX = 9 };
 struct ZstdFseEntry { uint8_t sym, nb; uint16_t base; };      // (read as one little-endian dword in the sequence loop)
 static_assert(sizeof(ZstdFseEntry) == 4, "one dword per entry");
 
+// ---- a frame WALKED instead of decoded (zstd_walk_kernel.h) ---------------------------------------------------------------
+// The entropy decoder needs tables and a bit stream, not the 32 KiB its output takes: a launch of walkers (eight waves a CU instead
+// of three) reads what the frames SAY into a plan in global memory -- per frame a list of ZstdOp, the sequences as 8-byte records,
+// the Huffman-coded literals decoded -- and a second launch, whose waves hold an output block and nothing else, replays the plans.
+enum : uint32_t { ZOP_RAW = 1, ZOP_FILL = 2, ZOP_SEQ = 3, ZOP_END = 4 };
+struct ZstdOp {
+    uint32_t kind;         // ZOP_*
+    uint32_t size;         // RAW / FILL: bytes of the block; SEQ: the block's literal bytes (regen); END: the frame's regenerated size
+    uint64_t ptr;          // RAW: where the bytes lie; FILL: the byte; SEQ: where the literals lie -- or, lit_fill set, the byte they all are
+    uint32_t nseq, rec;    // SEQ: its sequences are records rec .. rec + nseq - 1 of the plan
+    uint32_t lit_fill;     // SEQ: 1 = run-length literals
+    uint32_t stream;       // the stream of the blosc2 block this frame is
+};
+static_assert(sizeof(ZstdOp) == 32, "ops are read as two 16-byte loads");
+// a sequence: literal length | match length << 21 | offset << 42 (all three at most the output capacity, < 2^21)
+CIMG_HD uint64_t zstd_record(uint32_t ll, uint32_t ml, uint32_t of) { return (uint64_t)ll | ((uint64_t)ml << 21) | ((uint64_t)of << 42); }
+enum : int { ZSTD_WALK_OVERFLOW = -2000 };     // internal: the plan does not fit its slot -- the block goes to the decoder that needs none
+
 struct ZstdWork {
     uint16_t huf[1 << ZSTD_HUF_LOG_MAX];            // symbol | code length << 8: one load per decoded literal
-    ZstdFseEntry ll[1 << ZSTD_FSE_LOG_MAX], ml[1 << ZSTD_FSE_LOG_MAX], of[1 << ZSTD_FSE_LOG_MAX], wt[64];
+    ZstdFseEntry ll[1 << ZSTD_FSE_LOG_MAX], ml[1 << ZSTD_FSE_LOG_MAX], of[1 << (ZSTD_FSE_LOG_MAX - 1)], wt[64];   // (offset codes: table log <= 8)
     int16_t freq[256];
     uint16_t sdesc[256];
     uint8_t weights[256];
@@ -48,6 +66,11 @@ struct ZstdWork {
     int32_t tail;            // 1: the frame lies in global memory -- the section being decoded is copied to `stage` when it fits there
     int32_t stage_cap;       // bytes at stage
     uint8_t* stage;          // 16-byte aligned
+    // walker: ops == nullptr is the decoder proper.  Counts are in units (ops, records, bytes); *_n is where the next one goes.
+    ZstdOp* ops;
+    uint64_t* recs;
+    uint8_t* lits;
+    int32_t op_n, op_cap, rec_n, rec_cap, lit_n, lit_cap, stream, pad_;
 };
 
 // ---- bit readers --------------------------------------------------------------------------------------------------
@@ -631,7 +654,7 @@ extern long g_emu_zx_batches, g_emu_zx_rounds, g_emu_zx_par, g_emu_zx_serial, g_
 #endif
 template <class DP>
 CIMG_DEV int zstd_execute_batch(DP dst, int dcap, int* dpos_io, DP lit, int regen, int* lpos_io, int nb,
-                                const LV<int>& vll, const LV<int>& vml, const LV<int>& vof, const ZstdWork* w)
+                                const LV<int>& vll, const LV<int>& vml, const LV<int>& vof, const uint8_t* mlo_in, const uint8_t* mhi_in)
 {
     const int dpos = *dpos_io, lpos = *lpos_io;
     LV<int> len, opos, lsum, ll, ml, of;
@@ -656,8 +679,8 @@ CIMG_DEV int zstd_execute_batch(DP dst, int dcap, int* dpos_io, DP lit, int rege
         bad[l] = act[l] & ((of[l] <= 0) | (of[l] > M[l]));   // (the serial loop: offset > dpos once the literals are out)
     }
     if (ballot(bad)) return ERR_DATA;
-    const uint8_t* const mlo = w->mem_lo;
-    const uint8_t* const mhi = w->mem_hi;
+    const uint8_t* const mlo = reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(mlo_in)));
+    const uint8_t* const mhi = reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(mhi_in)));
 #ifdef CIMG_ABL_ZSTD_NO_EXEC      /* timing experiment only: nothing is copied */
     *dpos_io = dpos + acc; *lpos_io = lpos + ltot;
     if (acc >= 0) return 0;
@@ -799,6 +822,48 @@ CIMG_DEV int zstd_execute_batch(DP dst, int dcap, int* dpos_io, DP lit, int rege
     return 0;
 }
 
+// ---- what 64 sequences say -----------------------------------------------------------------------------------------------
+// Lane k holds sequence k's three table entries (symbol | state bits << 8 | state base << 16) and the bit position just above its
+// extra bits (offset's first = highest, then match length's, then literal length's).  Lengths and offset values are one lane's
+// arithmetic each; what stays serial is the history of repeat offsets (RFC 8878 3.1.1.5), a scalar walk over the batch.
+CIMG_DEV void zstd_resolve_batch(const uint8_t* bs_in, int bl_in, int nb_in, const LV<uint32_t>& vpl, const LV<uint32_t>& vpo, const LV<uint32_t>& vpm,
+                                         const LV<int>& vtop, LV<int>& vll, LV<int>& vml, LV<int>& vof, int& r0_io, int& r1_io, int& r2_io)
+{
+    const uint8_t* const bs = reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(bs_in)));
+    const int bl = uni(bl_in), nb = uni(nb_in);
+    int r0 = uni(r0_io), r1 = uni(r1_io), r2 = uni(r2_io);
+    LV<int> ov;
+    LV<bool> nolit, rep;
+    FOR_LANES(l) {
+        const bool act = l < nb;
+        const int ls = act ? (int)(vpl[l] & 0xFF) : 0, os = act ? (int)(vpo[l] & 31) : 2, ms = act ? (int)(vpm[l] & 0xFF) : 0;
+        const int xc = zstd_ll_bits(ls), xb = zstd_ml_bits(ms);
+        const int top = vtop[l];
+        const uint32_t xo = act ? zstd_rbits_lane(bs, bl, top, os) : 0u;
+        const uint32_t xm = act ? zstd_rbits_lane(bs, bl, top - os, xb) : 0u;
+        const uint32_t xl = act ? zstd_rbits_lane(bs, bl, top - os - xb, xc) : 0u;
+        vll[l] = zstd_ll_base(ls) + (int)xl;
+        vml[l] = act ? zstd_ml_base(ms) + (int)xm : 0;
+        ov[l] = (int)((1u << os) + xo);                         // (a lane beyond the batch: 4, i.e. nothing for the walk below)
+        vof[l] = ov[l] - 3;
+        nolit[l] = act & (vll[l] == 0);
+        rep[l] = act & ((uint32_t)ov[l] <= 3u);
+    }
+    const uint64_t zl = ballot(nolit), reps = ballot(rep);
+    // the history: a new offset pushes the three down; a repeat code picks one of them (one further when the sequence has no
+    // literals; the fourth choice is the first offset minus one) and moves it to the front
+    for (int k = 0; k < nb; ++k) {
+        if (!((reps >> k) & 1)) { r2 = r1; r1 = r0; r0 = uni(readlane(vof, k)); continue; }
+        const int idx = uni(readlane(ov, k)) + (int)((zl >> k) & 1);
+        int offset;
+        if (idx == 1) offset = r0;
+        else if (idx == 2) { offset = r1; r1 = r0; r0 = offset; }
+        else { offset = idx == 3 ? r2 : r0 - 1; r2 = r1; r1 = r0; r0 = offset; }
+        writelane(vof, k, offset);
+    }
+    r0_io = r0; r1_io = r1; r2_io = r2;
+}
+
 // ---- the sequences section of one block (round 4: out of line, tables and bit stream through LDS-typed pointers) ------------
 // Until round 3 this loop was part of zstd_block, inlined into a kernel of ten thousand instructions: 197 spilled scalars, and --
 // because the work area reaches it through a pointer the compiler cannot trace to the __shared__ array -- every table entry and
@@ -843,7 +908,7 @@ template <class BP> struct ZstdBits {                     // the backward bit re
                 __builtin_memcpy(&c, src + (lo >> 3), 8);
                 cont = (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
             }
-            return (uint32_t)(cont >> (t - lo)) & (uint32_t)((1ull << n) - 1);
+            return (uint32_t)(cont >> ((t - lo) & 63)) & (uint32_t)((1ull << n) - 1);      // (t - lo == 64 only with n == 0: a byte-aligned reader that stands still)
         }
         return uni(zstd_bits_slow<BP>(src, size, t, n));   // (uni: what a real call returns arrives in a vector register)
     }
@@ -859,7 +924,7 @@ template <class BP> struct ZstdBits {                     // the backward bit re
             cont = (uint64_t)uni((uint32_t)c) | ((uint64_t)uni((uint32_t)(c >> 32)) << 32);
         }
         off = t;
-        return (uint32_t)(cont >> (t - lo)) & (uint32_t)((1ull << n) - 1);
+        return (uint32_t)(cont >> ((t - lo) & 63)) & (uint32_t)((1ull << n) - 1);      // (t - lo == 64 only with n == 0: a byte-aligned reader that stands still)
     }
 };
 // length codes above the directly coded ones (literal lengths from 16, match lengths from 35): (base << 8) | extra bits
@@ -868,7 +933,7 @@ CIMG_DEV_OUTLINE uint32_t zstd_ml_code_slow(int c_in) { const int c = uni(c_in);
 
 CIMG_DEV int32_t zstd_field(const int32_t* p) { return (int32_t)uni((uint32_t)*p); }
 
-template <class BP>
+template <class BP, bool WALK = false>
 CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
 {
     ZstdWork* const w = reinterpret_cast<ZstdWork*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w_in)));
@@ -884,13 +949,19 @@ CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
     uint8_t* const dst = reinterpret_cast<uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->seq_dst)));
     const uint8_t* const lit = reinterpret_cast<const uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->seq_lit)));
     int r0 = zstd_field(&w->r0), r1 = zstd_field(&w->r1), r2 = zstd_field(&w->r2);
+    int rec_n = WALK ? zstd_field(&w->rec_n) : 0;
+    uint64_t* const recs = WALK ? reinterpret_cast<uint64_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->recs))) : nullptr;
     const BP bs = (BP)bs_g;
     ZstdBits<BP> br;
     br.init(bs, bl, bl * 8 - (8 - zstd_highbit(uni((uint32_t)bs[bl - 1]))));
     const int llm = (1 << ll_log) - 1, ofm = (1 << of_log) - 1, mlm = (1 << ml_log) - 1;
     int sl = (int)br.get(ll_log), so = (int)br.get(of_log), sm = (int)br.get(ml_log);
-    LV<int> vll, vml, vof;                                 // lane k: sequence k of the current batch of 64
-    FOR_LANES(l) { vll[l] = 0; vml[l] = 0; vof[l] = 1; }
+    // The loop below is the SERIAL part of a sequence and nothing else: the three states walk down the bit stream.  What a sequence
+    // says -- its lengths and its offset -- is read afterwards, 64 sequences at a time, one lane each (zstd_resolve_batch): lane k
+    // keeps sequence k's three table entries and the bit position just above its extra bits.
+    LV<uint32_t> vpl, vpo, vpm;
+    LV<int> vtop;
+    FOR_LANES(l) { vpl[l] = 0; vpo[l] = 0; vpm[l] = 0; vtop[l] = 0; }
     // (the entries travel from one iteration to the next in VECTOR registers -- that is where a load lands -- and are made scalar at
     // the top of the iteration that uses them: carried as scalars they would have to be waited for in the iteration that requests
     // them; carried as vectors WITHOUT the uni() up here the compiler takes the whole loop for divergent control flow)
@@ -906,24 +977,14 @@ CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
         const int os = (int)(po & 0xFF), onb = (int)((po >> 8) & 0xFF), obase = (int)(po >> 16);
         const int ms = (int)(pm & 0xFF), mnb = (int)((pm >> 8) & 0xFF), mbase = (int)(pm >> 16);
         if (!FAST && (os > 31 || ls > 35 || ms > 52)) { err = ERR_DATA; return; }
-        // The extra bits of offset, match length and literal length lie one behind the other in the stream (first read = highest
-        // bits), and so do the three state updates: one read each when they fit 32 bits (they nearly always do) instead of three.
-        // (most sequences of an image have a literal length below 16 and a match length below 35: coded directly, no extra bits)
-        int xb = 0, xc = 0, mlen = ms + 3, llen = ls;
-        if (ms >= 32) { const uint32_t q = uni(zstd_ml_code_slow(ms)); xb = (int)(q & 0xFF); mlen = (int)(q >> 8); }
-        if (ls >= 16) { const uint32_t q = uni(zstd_ll_code_slow(ls)); xc = (int)(q & 0xFF); llen = (int)(q >> 8); }
-        const int xa = os & 31;
-        uint32_t xo;
-        if (xa + xb + xc <= 32) {
-            const uint32_t V = FAST ? br.getf(xa + xb + xc) : br.get(xa + xb + xc);
-            if (xb | xc) {
-                llen += (int)(V & ((1u << xc) - 1));
-                mlen += (int)((V >> xc) & ((1u << xb) - 1));
-                xo = xa ? V >> (xb + xc) : 0;
-            } else xo = V;
-        } else if (FAST) { xo = br.getf(xa); mlen += (int)br.getf(xb); llen += (int)br.getf(xc); }
-        else { xo = br.get(xa); mlen += (int)br.get(xb); llen += (int)br.get(xc); }
-        const uint32_t ov = (1u << xa) + xo;
+        // the extra bits of offset, match length and literal length lie one behind the other in the stream: stepped over here
+        // (most sequences of an image have a literal length below 16 and a match length below 32: coded directly, no extra bits)
+        int extra = os & 31;
+        if (ms >= 32) extra += zstd_ml_bits(ms);
+        if (ls >= 16) extra += zstd_ll_bits(ls);
+        const int k = i & 63;
+        writelane(vtop, k, br.off); writelane(vpl, k, pl); writelane(vpo, k, po); writelane(vpm, k, pm);
+        br.off -= extra;
         if (i + 1 < nseq) {
             const uint32_t V = FAST ? br.getf(lnb + mnb + onb) : br.get(lnb + mnb + onb);               // <= 9 + 9 + 8 bits
             so = obase + (int)(V & ((1u << onb) - 1));
@@ -933,17 +994,6 @@ CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
             pl_v = tll[sl & llm]; po_v = tof[so & ofm]; pm_v = tml[sm & mlm];
         }
         if (!FAST && br.off < 0) { err = ERR_DATA; return; }
-        // (three named scalars, no indexing by idx: a dynamically indexed private array is scratch memory on the device)
-        int offset;
-        if (ov > 3) { offset = (int)(ov - 3); r2 = r1; r1 = r0; r0 = offset; }
-        else {
-            const int idx = (int)ov + (llen == 0 ? 1 : 0);
-            if (idx == 1) offset = r0;
-            else if (idx == 2) { offset = r1; r1 = r0; r0 = offset; }
-            else { offset = idx == 3 ? r2 : r0 - 1; r2 = r1; r1 = r0; r0 = offset; }
-        }
-        const int k = i & 63;
-        writelane(vll, k, llen); writelane(vml, k, mlen); writelane(vof, k, offset);
     };
     for (int i = 0; i < nseq; i++) {
         if (bl >= 8 && br.off >= 96) step(std::true_type{}, i);
@@ -951,19 +1001,56 @@ CIMG_DEV_OUTLINE int zstd_sequences(ZstdWork* w_in)
         if (err) return err;
         const int k = i & 63;
         if (k == 63 || i + 1 == nseq) {
-            // (the output area -- and the literals at its end -- lie in LDS whenever this is the LDS instance)
-            using DP = typename std::conditional<in_lds, cimg_lds_u8p, uint8_t*>::type;
-            const int rc = zstd_execute_batch<DP>((DP)dst, dcap, &dpos, (DP)const_cast<uint8_t*>(lit), regen, &lpos, k + 1, vll, vml, vof, w);
-            if (rc < 0) return rc;
+            LV<int> vll, vml, vof;
+            zstd_resolve_batch(bs_g, bl, k + 1, vpl, vpo, vpm, vtop, vll, vml, vof, r0, r1, r2);
+            if constexpr (WALK) {
+                // the walker: the batch becomes records of the plan (one 8-byte store a lane), after the checks of the executor
+                // that need no output -- the replay makes the others
+                const int nb = k + 1;
+                LV<bool> bad;
+                LV<int> len, t0, t1;
+                FOR_LANES(l) {
+                    const bool act = l < nb;
+                    if (!act) { vll[l] = 0; vml[l] = 0; vof[l] = 1; }
+                    bad[l] = act & ((vll[l] < 0) | (vml[l] < 0) | (vll[l] > regen) | (vml[l] > dcap) | (vof[l] <= 0) | (vof[l] > dcap));
+                    len[l] = bad[l] ? 0 : vll[l] + vml[l];
+                    if (bad[l]) vll[l] = 0;
+                }
+                if (ballot(bad)) return ERR_DATA;
+                int acc, ltot;
+                wave_exscan(len, t0, acc);
+                wave_exscan(vll, t1, ltot);
+                if (ltot > regen - lpos || acc > dcap - dpos) return ERR_DATA;
+                FOR_LANES_W(l) { if (l < nb) recs[rec_n + l] = zstd_record((uint32_t)vll[l], (uint32_t)vml[l], (uint32_t)vof[l]); }
+                rec_n += nb; dpos += acc; lpos += ltot;
+            } else {
+                // (the output area -- and the literals at its end -- lie in LDS whenever this is the LDS instance)
+                using DP = typename std::conditional<in_lds, cimg_lds_u8p, uint8_t*>::type;
+                const int rc = zstd_execute_batch<DP>((DP)dst, dcap, &dpos, (DP)const_cast<uint8_t*>(lit), regen, &lpos, k + 1, vll, vml, vof, w->mem_lo, w->mem_hi);
+                if (rc < 0) return rc;
+            }
         }
     }
     if (br.off != 0) return ERR_DATA;
-    FOR_LANES_W(l) { w->seq_lpos = lpos; w->r0 = r0; w->r1 = r1; w->r2 = r2; }
+    FOR_LANES_W(l) { w->seq_lpos = lpos; w->r0 = r0; w->r1 = r1; w->r2 = r2; if (WALK) w->rec_n = rec_n; }
     return dpos;
 }
 
 // ---- one compressed block ---------------------------------------------------------------------------------------------
 struct ZstdFrameState { int r0, r1, r2; };      // the three repeat offsets
+
+CIMG_DEV bool zstd_walking(const ZstdWork* w) { return uni64((int64_t)reinterpret_cast<uintptr_t>(w->ops)) != 0; }
+// the walker's next op (its stream number is filled in here)
+CIMG_DEV int zstd_emit(ZstdWork* w, ZstdOp op)
+{
+    const int n = zstd_field(&w->op_n);
+    if (n >= zstd_field(&w->op_cap)) return ZSTD_WALK_OVERFLOW;
+    op.stream = (uint32_t)zstd_field(&w->stream);
+    ZstdOp* const to = reinterpret_cast<ZstdOp*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->ops))) + n;
+    FOR_LANES_W(l) { if (l == 0) *to = op; }
+    FOR_LANES_W(l) { w->op_n = n + 1; }
+    return 0;
+}
 
 CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, int dcap, ZstdWork* w, ZstdFrameState* fs)
 {
@@ -989,7 +1076,17 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
     // fails the bounds checks below, possibly after garbling literals of its own -- all of it inside dst.)  Copies run in
     // ascending 64-byte steps, load before store, which is safe for a source AT OR ABOVE its destination.
     if (regen > dcap - dpos) return ERR_DATA;
-    uint8_t* const litbuf = dst + (dcap - regen);
+    // (a walker has no output: coded literals are decoded into the plan's literal area, raw ones stay where they lie, a run is one byte)
+    const bool walk = zstd_walking(w);
+    uint64_t lit_word = 0;                                 // walker: what the SEQ op says about the literals
+    uint32_t lit_fill = 0;
+    uint8_t* litbuf;
+    if (walk) {
+        const int at = zstd_field(&w->lit_n);
+        if (ltype >= 2 && regen > zstd_field(&w->lit_cap) - at) return ZSTD_WALK_OVERFLOW;
+        litbuf = reinterpret_cast<uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->lits))) + at;
+        if (ltype >= 2) { FOR_LANES_W(l) { w->lit_n = at + ((regen + 15) & ~15); } lit_word = (uint64_t)reinterpret_cast<uintptr_t>(litbuf); }
+    } else litbuf = dst + (dcap - regen);
     int pos = hdr;
     const uint8_t* lit = litbuf;
     // A frame in global memory (w->tail): every bit read and every literal run would wait for a load from there, once per
@@ -998,11 +1095,13 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
     const int stage_cap = w->tail ? w->stage_cap : 0;
     if (ltype == 0) {
         if (pos + regen > size) return ERR_DATA;
-        zstd_stage(litbuf, src + pos, regen);              // (also from a frame in LDS: the batch executor reads its literals from the output area)
+        if (walk) lit_word = (uint64_t)reinterpret_cast<uintptr_t>(src + pos);
+        else zstd_stage(litbuf, src + pos, regen);         // (also from a frame in LDS: the batch executor reads its literals from the output area)
         pos += regen;
     } else if (ltype == 1) {
         if (pos + 1 > size) return ERR_DATA;
-        zstd_fill(litbuf, zstd_u8(src, pos), regen);
+        if (walk) { lit_word = (uint64_t)zstd_u8(src, pos); lit_fill = 1; }
+        else zstd_fill(litbuf, zstd_u8(src, pos), regen);
         pos += 1;
     } else {
         if (pos + comp > size) return ERR_DATA;
@@ -1061,6 +1160,7 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         else { if (pos + 1 > size) return ERR_DATA; nseq = ((nseq - 128) << 8) + zstd_u8(src, pos++); }
     }
     int lpos = 0;                                          // literals consumed
+    int rec_first = 0;
     if (nseq > 0) {
         if (pos >= size) return ERR_DATA;
         const int modes = zstd_u8(src, pos++);
@@ -1104,7 +1204,13 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
 #ifdef CIMG_ABL_ZSTD_NO_SEQ      /* timing experiment only */
         if (nseq >= 0) return dpos;
 #endif
-        const int rc = (bs_lds && zstd_field((const int32_t*)&w->seq_bs_lds) && w->mem_lo != nullptr) ? zstd_sequences<cimg_lds_cu8p>(w) : zstd_sequences<const uint8_t*>(w);
+        const bool typed = bs_lds && zstd_field((const int32_t*)&w->seq_bs_lds) && w->mem_lo != nullptr;
+        int rc;
+        if (walk) {
+            if (nseq > zstd_field(&w->rec_cap) - zstd_field(&w->rec_n)) return ZSTD_WALK_OVERFLOW;
+            rec_first = zstd_field(&w->rec_n);
+            rc = typed ? zstd_sequences<cimg_lds_cu8p, true>(w) : zstd_sequences<const uint8_t*, true>(w);
+        } else rc = typed ? zstd_sequences<cimg_lds_cu8p>(w) : zstd_sequences<const uint8_t*>(w);
         if (rc < 0) return rc;
         dpos = rc;
         lpos = zstd_field(&w->seq_lpos);
@@ -1112,11 +1218,18 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
     }
     const int rest = regen - lpos;
     if (rest > dcap - dpos) return ERR_DATA;
-    zstd_copy(dst + dpos, lit + lpos, rest);
+    if (walk) {
+        ZstdOp op;
+        op.kind = ZOP_SEQ; op.size = (uint32_t)regen; op.ptr = lit_word; op.nseq = (uint32_t)nseq; op.rec = (uint32_t)rec_first; op.lit_fill = lit_fill; op.stream = 0;
+        const int rc = zstd_emit(w, op);
+        if (rc < 0) return rc;
+    } else zstd_copy(dst + dpos, lit + lpos, rest);
     return dpos + rest;
 }
 
 // One frame at src[0, size) -> dst[0, cap).  Returns the regenerated size or a negative blosc2 error code.
+// A walker (w->ops set; dst unused) leaves the frame's ops, records and coded literals in its plan instead: zstd_replay_frame below
+// is the other half.  ZSTD_WALK_OVERFLOW: the plan's slot is too small for this frame.
 CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int cap, ZstdWork* w)
 {
     if (size < 6) return ERR_DATA;
@@ -1137,6 +1250,7 @@ CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int c
     }
     pos += fcs_bytes;
     w->have_huf = 0; w->have_tables = 0;
+    const bool walk = zstd_walking(w);
     ZstdFrameState fs;
     fs.r0 = 1; fs.r1 = 4; fs.r2 = 8;
     int dpos = 0;
@@ -1147,11 +1261,21 @@ CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int c
         const int last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
         if (type == 0) {
             if (pos + bsz > size || bsz > cap - dpos) return ERR_DATA;
-            zstd_copy(dst + dpos, src + pos, bsz);
+            if (walk) {
+                ZstdOp op;
+                op.kind = ZOP_RAW; op.size = (uint32_t)bsz; op.ptr = (uint64_t)reinterpret_cast<uintptr_t>(src + pos); op.nseq = 0; op.rec = 0; op.lit_fill = 0; op.stream = 0;
+                const int rc = zstd_emit(w, op);
+                if (rc < 0) return rc;
+            } else zstd_copy(dst + dpos, src + pos, bsz);
             dpos += bsz; pos += bsz;
         } else if (type == 1) {
             if (pos + 1 > size || bsz > cap - dpos) return ERR_DATA;
-            zstd_fill(dst + dpos, zstd_u8(src, pos), bsz);
+            if (walk) {
+                ZstdOp op;
+                op.kind = ZOP_FILL; op.size = (uint32_t)bsz; op.ptr = (uint64_t)zstd_u8(src, pos); op.nseq = 0; op.rec = 0; op.lit_fill = 0; op.stream = 0;
+                const int rc = zstd_emit(w, op);
+                if (rc < 0) return rc;
+            } else zstd_fill(dst + dpos, zstd_u8(src, pos), bsz);
             dpos += bsz; pos += 1;
         } else if (type == 2) {
             if (pos + bsz > size) return ERR_DATA;
@@ -1163,8 +1287,74 @@ CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int c
             if (checksum) pos += 4;
             if (pos > size) return ERR_DATA;
             if (fcs >= 0 && fcs != dpos) return ERR_DATA;
+            if (walk) {
+                ZstdOp op;
+                op.kind = ZOP_END; op.size = (uint32_t)dpos; op.ptr = 0; op.nseq = 0; op.rec = 0; op.lit_fill = 0; op.stream = 0;
+                const int rc = zstd_emit(w, op);
+                if (rc < 0) return rc;
+            }
             return dpos;
         }
+    }
+    return ERR_DATA;
+}
+
+// ---- the other half of a walked frame -------------------------------------------------------------------------------------
+// ops[first ..] up to the frame's ZOP_END -> dst[0, cap), the way zstd_decode_frame writes it: raw and run blocks, and of a
+// compressed block the literals brought to the end of the output, its records executed 64 at a time (the next 64 are requested
+// before the current ones are executed), the literals behind the last sequence.  Nothing a record says is trusted: the batch
+// executor checks lengths, offsets and positions against the output as it does for the decoder proper.  Returns the regenerated
+// size (and the index behind the frame's last op) or a negative error code.
+template <class DP>
+CIMG_DEV int zstd_replay_frame(const ZstdOp* ops_in, int first_in, int nops_in, int stream_in, const uint64_t* recs_in, int nrecs_in,
+                               uint8_t* dst, int cap, const uint8_t* mlo, const uint8_t* mhi, int* next_op)
+{
+    const ZstdOp* const ops = reinterpret_cast<const ZstdOp*>(uni64((int64_t)reinterpret_cast<uintptr_t>(ops_in)));
+    const uint64_t* const recs = reinterpret_cast<const uint64_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(recs_in)));
+    const int first = uni(first_in), nops = uni(nops_in), stream = uni(stream_in), nrecs = uni(nrecs_in);
+    int dpos = 0;
+    for (int i = first; i < nops; ++i) {
+        const uint32_t* const q = reinterpret_cast<const uint32_t*>(ops + i);
+        const uint32_t kind = uni(q[0]), size = uni(q[1]), p_lo = uni(q[2]), p_hi = uni(q[3]), nseq = uni(q[4]), rec = uni(q[5]), lit_fill = uni(q[6]), st = uni(q[7]);
+        const uint64_t ptr = (uint64_t)p_lo | ((uint64_t)p_hi << 32);
+        if ((int)st != stream || (int)size < 0) return ERR_DATA;
+        if (kind == ZOP_END) {
+            if ((int)size != dpos) return ERR_DATA;
+            *next_op = i + 1;
+            return dpos;
+        }
+        if ((int)size > cap - dpos) return ERR_DATA;
+        if (kind == ZOP_RAW) {
+            zstd_stage(dst + dpos, reinterpret_cast<const uint8_t*>((uintptr_t)ptr), (int)size);
+            dpos += (int)size;
+        } else if (kind == ZOP_FILL) {
+            zstd_fill(dst + dpos, (uint8_t)ptr, (int)size);
+            dpos += (int)size;
+        } else if (kind == ZOP_SEQ) {
+            const int regen = (int)size;
+            uint8_t* const litbuf = dst + (cap - regen);
+            if (lit_fill) zstd_fill(litbuf, (uint8_t)ptr, regen);
+            else zstd_stage(litbuf, reinterpret_cast<const uint8_t*>((uintptr_t)ptr), regen);
+            if ((int)nseq < 0 || (int)rec < 0 || (int64_t)rec + nseq > (int64_t)nrecs) return ERR_DATA;
+            int lpos = 0;
+            LV<uint64_t> cur, nxt;
+            FOR_LANES(l) { cur[l] = l < (int)nseq ? recs[rec + l] : 0; nxt[l] = 0; }
+            for (int b = 0; b < (int)nseq; b += 64) {
+                const int nb = imin(64, (int)nseq - b);
+                FOR_LANES(l) { if (b + 64 + l < (int)nseq) nxt[l] = recs[rec + b + 64 + l]; }
+                LV<int> vll, vml, vof;
+                FOR_LANES(l) {
+                    vll[l] = (int)(cur[l] & 0x1FFFFF); vml[l] = (int)((cur[l] >> 21) & 0x1FFFFF); vof[l] = (int)(cur[l] >> 42);
+                }
+                const int rc = zstd_execute_batch<DP>((DP)dst, cap, &dpos, (DP)litbuf, regen, &lpos, nb, vll, vml, vof, mlo, mhi);
+                if (rc < 0) return rc;
+                FOR_LANES(l) { cur[l] = nxt[l]; }
+            }
+            const int rest = regen - lpos;
+            if (rest > cap - dpos) return ERR_DATA;
+            zstd_copy(dst + dpos, litbuf + lpos, rest);
+            dpos += rest;
+        } else return ERR_DATA;
     }
     return ERR_DATA;
 }

@@ -32,6 +32,60 @@ CIMG_HD int zstd_kernel_lds_bytes(int max_blocksize, int waves) { return zstd_ke
 extern int g_emu_zstd_take;
 #endif
 
+// What the three kernels of the zstd read path first learn about block b: whose it is, its geometry, where its streams begin.
+struct ZstdBlockGeom {
+    int chunk, j, bsize, ns, neblock, ts, filter, cbytes, bstart;
+    bool split_chunk;
+    const uint8_t* c;
+    uint8_t* out;
+    // 1: a block of a zstd chunk; 0: not ours (whatever cimg_decode_blocks already settled -- damaged headers, special and memcpyed
+    // chunks, its own codecs -- or, kind_of_launch = 1 / 2, a chunk of the other launch's kind); < 0: the block's error code
+    CIMG_DEV int parse(const DecodeArgs& a, int b, int area, int kind_of_launch)
+    {
+        chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
+        const ChunkDesc d = uniform_desc(a.descs + chunk);
+        j = b - d.blk0;
+        c = a.comp + d.comp_off;
+        out = a.raw + d.raw_off + (int64_t)j * d.blocksize;
+        bsize = (j == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
+        const u128 h0 = ld128u(c), h1 = ld128u(c + 16);
+        const uint32_t w0 = uni(h0.x);
+        const int flags = (int)((w0 >> 16) & 0xFF);
+        ts = (int)(w0 >> 24);
+        const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z);
+        cbytes = (int)uni(h0.w);
+        const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
+        bool ours = !((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN || cbytes > d.destsize);
+        ours = ours && (flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) == (FLAG_SHUFFLE | FLAG_BITSHUFFLE);
+        ours = ours && ((b2 >> 28) & 7) == 0 && !(flags & FLAG_MEMCPYED);
+        ours = ours && (flags >> 5) == 4;                                     // its own codecs, and formats nobody reads (reported already)
+        split_chunk = !(flags & FLAG_DONT_SPLIT) && ts > 1;
+        if (ours && kind_of_launch && split_chunk != (kind_of_launch == 2)) ours = false;
+        if (!ours) return 0;
+        filter = (int)((f1 >> 8) & 0xFF);
+        if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE)) return ERR_CODEC_SUPPORT;
+        if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) return ERR_CODEC_SUPPORT;          // bit rows are never split
+        if (area < ZSTD_KERNEL_AREA_MIN || blocksize > area) return ERR_CODEC_SUPPORT;
+        const bool leftover_blk = bsize != blocksize;
+        ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
+        neblock = bsize / ns;
+        if (cbytes < HEADER_LEN + 4 * d.nblocks) return ERR_READ_BUFFER;
+        bstart = ld32s(c + HEADER_LEN + 4 * j);
+        if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) return ERR_DATA;
+        return 1;
+    }
+    // the size word of the stream at pos (pos moves behind it); payload = the bytes the stream takes behind the word
+    CIMG_DEV int stream_header(int& pos, int& cs, int& payload) const
+    {
+        if (cbytes - pos < 4) return ERR_READ_BUFFER;
+        cs = uni(ld32s(c + pos));
+        pos += 4;
+        payload = cs > 0 ? cs : (cs < 0 ? 1 : 0);
+        if (payload > cbytes - pos) return ERR_READ_BUFFER;
+        return 0;
+    }
+};
+
 struct DecodeZstdBlock {
     const DecodeArgs& a;
     uint8_t* lds;
@@ -55,37 +109,19 @@ struct DecodeZstdBlock {
     CIMG_DEV void phase_a(int wv)
     {
         area = (a.lds_bytes - 64 - nw * (ZSTD_KERNEL_STAGE + zstd_work_bytes()) - ZSTD_KERNEL_CTL) & ~63;
-        chunk = find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks);
-        const ChunkDesc d = uniform_desc(a.descs + chunk);
-        j = b - d.blk0;
-        c = a.comp + d.comp_off;
-        out = a.raw + d.raw_off + (int64_t)j * d.blocksize;
-        bsize = (j == d.nblocks - 1 && d.leftover) ? d.leftover : d.blocksize;
-        const u128 h0 = ld128u(c), h1 = ld128u(c + 16);
-        const uint32_t w0 = uni(h0.x);
-        const int flags = (int)((w0 >> 16) & 0xFF);
-        ts = (int)(w0 >> 24);
-        const int nbytes = (int)uni(h0.y), blocksize = (int)uni(h0.z), cbytes = (int)uni(h0.w);
-        const uint32_t f0 = uni(h1.x), f1 = uni(h1.y), b2 = uni(h1.w);
-        // whatever cimg_decode_blocks already settled -- damaged headers, special and memcpyed chunks, its own codecs -- is not ours
-        bool ours = !((w0 & 0xFF) > 5 || nbytes != d.nbytes || blocksize != d.blocksize || ts == 0 || cbytes < HEADER_LEN || cbytes > d.destsize);
-        ours = ours && (flags & (FLAG_SHUFFLE | FLAG_BITSHUFFLE)) == (FLAG_SHUFFLE | FLAG_BITSHUFFLE);
-        ours = ours && ((b2 >> 28) & 7) == 0 && !(flags & FLAG_MEMCPYED);
-        ours = ours && (flags >> 5) == 4;                                     // its own codecs, and formats nobody reads (reported already)
+        ZstdBlockGeom g;
         // (a split chunk is the two-wave launch's, every other one the one-wave launch's, when a batch has both: a.tune says so)
-        const bool split_chunk = !(flags & FLAG_DONT_SPLIT) && ts > 1;
-        if (ours && a.tune == 1 && split_chunk != (nw > 1)) ours = false;
-        if (!ours) { report(wv, ZSTD_BLOCK_NOT_OURS, 0); return; }
-        filter = (int)((f1 >> 8) & 0xFF);
-        if (f0 != 0 || (f1 & 0xFF) != 0 || (filter != FILTER_NONE && filter != FILTER_SHUFFLE && filter != FILTER_BITSHUFFLE)) { report(wv, -1, ERR_CODEC_SUPPORT); return; }
-        if (filter == FILTER_BITSHUFFLE && !(flags & FLAG_DONT_SPLIT)) { report(wv, -1, ERR_CODEC_SUPPORT); return; }          // bit rows are never split
-        if (area < ZSTD_KERNEL_AREA_MIN || blocksize > area) { report(wv, -1, ERR_CODEC_SUPPORT); return; }
-        const bool leftover_blk = bsize != blocksize;
-        ns = (!(flags & FLAG_DONT_SPLIT) && !leftover_blk) ? ts : 1;
-        neblock = bsize / ns;
-        if (cbytes < HEADER_LEN + 4 * d.nblocks) { report(wv, -1, ERR_READ_BUFFER); return; }
-        const int bstart = ld32s(c + HEADER_LEN + 4 * j);
-        if (bstart < HEADER_LEN + 4 * d.nblocks || bstart > cbytes) { report(wv, -1, ERR_DATA); return; }
+        int ours = g.parse(a, b, area, a.tune == 1 ? (nw > 1 ? 2 : 1) : 0);
+        chunk = g.chunk; j = g.j; bsize = g.bsize; ts = g.ts; c = g.c; out = g.out;
+        // (behind the walk / replay launches: only the blocks whose plan did not fit its slot)
+        if (ours != 0 && a.zplan != nullptr) {
+            const int32_t* const head = reinterpret_cast<const int32_t*>(a.zplan + (int64_t)(b - a.blk_first) * a.zplan_stride);
+            if ((int)uni((uint32_t)head[0]) != 2) ours = 0;
+        }
+        if (ours == 0) { report(wv, ZSTD_BLOCK_NOT_OURS, 0); return; }
+        if (ours < 0) { report(wv, -1, ours); return; }
+        filter = g.filter; ns = g.ns; neblock = g.neblock;
+        const int cbytes = g.cbytes, bstart = g.bstart;
         // this wave's stage and tables.  A frame of at most ZSTD_KERNEL_STAGE bytes is copied into LDS whole -- the decoder reads it
         // bit by bit, and an LDS read is a fifth of a global one; of a larger one, each block's sections go through the same bytes
         // when they fit (ZstdWork::tail)
@@ -94,6 +130,7 @@ struct DecodeZstdBlock {
         ZstdWork* w = reinterpret_cast<ZstdWork*>(stage + ZSTD_KERNEL_STAGE);
         w->stage = stage;
         w->stage_cap = ZSTD_KERNEL_STAGE;
+        w->ops = nullptr;                                      // (the decoder proper: zstd_decode.h has a walker's form as well)
         w->mem_lo = lds;                                       // (the executor's 16-byte fetches may look anywhere in this workgroup's LDS)
         w->mem_hi = lds + (a.lds_bytes & ~3);
         // The stream headers are a chain (a stream begins where the one before it ends): a wave walks it from the last stream it

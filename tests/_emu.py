@@ -76,6 +76,18 @@ def set_write_order(o):
     lib().emu_set_write_order(o)
 
 
+def set_zstd_plan(cap):
+    """The zstd read path of the emulated batch decode: -1 = walk + replay launches with plans of the block area (the engine's
+    default), 0 = the fused kernels only, n = plans of n bytes (small: plans overflow and their blocks go to the fused kernels)."""
+    lib().emu_set_zstd_plan(int(cap))
+
+
+def zstd_refused():
+    """Blocks whose plan did not fit its slot since the last call."""
+    lib().emu_zstd_refused.restype = C.c_long
+    return int(lib().emu_zstd_refused())
+
+
 def set_lean(on):
     """Run (default) or skip the lean decode kernel in front of the general one."""
     lib().emu_set_lean(1 if on else 0)

@@ -5,6 +5,7 @@
 #define CIMG_EMULATE 1
 #include "plan.h"
 #include "zstd_kernel.h"
+#include "zstd_walk_kernel.h"
 #include "deinterleave_kernel.h"
 #include "assemble_kernel.h"
 #include "blosclz_kernel.h"
@@ -25,6 +26,8 @@ int g_emu_zstd_take = 1 << 30; long g_emu_zx_batches = 0, g_emu_zx_rounds = 0, g
 namespace cimg { long g_emu_d2[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
 namespace cimg { long g_emu_dec_par = 0, g_emu_dec_serial = 0, g_emu_dec_batches = 0; int g_emu_write_order = 0; long g_emu_windows = 0, g_emu_matches = 0, g_emu_collisions = 0; }
 using namespace cimg;
+static int g_emu_zstd_plan_cap = -1;    // -1: the block area (the engine's default); 0: no plans (fused kernels only); n: n bytes of records / literals a plan
+static long g_emu_zstd_refused = 0;
 static int g_emu_block_items = 1;     // tests also run the one-item-per-plane form
 
 extern "C" {
@@ -122,6 +125,8 @@ extern "C" void emu_set_lean_shape(int shape) { g_emu_lean_shape = shape; }
 int g_emu_lean = 1;            // tests switch the lean kernel off to cover the general one on every block
 long g_emu_lean_blocks = 0;    // blocks the lean kernel produced since the last emu_stats reset
 extern "C" void emu_set_lean(int on) { g_emu_lean = on; }
+extern "C" void emu_set_zstd_plan(int cap) { g_emu_zstd_plan_cap = cap; }
+extern "C" long emu_zstd_refused() { const long r = g_emu_zstd_refused; g_emu_zstd_refused = 0; return r; }
 extern "C" long emu_lean_blocks(void) { const long n = g_emu_lean_blocks; g_emu_lean_blocks = 0; return n; }
 
 int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_off, const int32_t* nbytes,
@@ -173,12 +178,47 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     for (int i = 0; i < nchunks; i++) if (status[i] == STATUS_ZSTD_PENDING || status[i] == STATUS_ZSTD_PENDING_SPLIT) { unread[status[i] == STATUS_ZSTD_PENDING_SPLIT] = true; status[i] = 0; }
     int max_bs = 0;
     for (const ChunkDesc& d : plan.descs) max_bs = d.blocksize > max_bs ? d.blocksize : max_bs;
+    // The engine's order (engine.hip: decompress_finish): the walk launch (plans in "global memory"), the replay launch, and behind
+    // them the fused kernels for the blocks whose plan did not fit its slot -- everything, when the planner is switched off
+    // (emu_set_zstd_plan: cap 0 = fused only; a small cap makes plans overflow).
+    std::vector<uint8_t> zplan;
+    uint32_t refused = 0;
+    DecodeArgs zb = da;
+    zb.done = nullptr;
+    const bool planned = (unread[0] || unread[1]) && g_emu_zstd_plan_cap != 0;
+    if (planned) {
+        const int area = zstd_kernel_area(max_bs);
+        const int cap = g_emu_zstd_plan_cap > 0 ? g_emu_zstd_plan_cap : area;
+        const int64_t stride = zstd_plan_stride(cap);
+        zplan.assign((size_t)plan.total_blocks * (size_t)stride, 0xCD);
+        zb.skipped = &refused;
+        zb.zplan = zplan.data(); zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.blk_first = 0;
+        DecodeArgs wa = zb;
+        wa.lds_bytes = zstd_walk_lds_bytes();
+        std::vector<uint8_t> wl((size_t)wa.lds_bytes + EMU_LDS_SLACK);
+        for (int b = 0; b < plan.total_blocks; b++) {
+            memset(wl.data(), 0xCD, wl.size());
+            ZstdWalkBlock blk(wa, wl.data(), b);
+            blk.run();
+        }
+        DecodeArgs ra = zb;
+        ra.lds_bytes = zstd_replay_lds_bytes(max_bs);
+        std::vector<uint8_t> rl((size_t)ra.lds_bytes);            // (exactly: the replay's dword fetches stay inside the launch's LDS)
+        for (int b = 0; b < plan.total_blocks; b++) {
+            memset(rl.data(), 0xCD, rl.size());
+            ZstdReplayBlock blk(ra, rl.data(), b);
+            blk.run();
+        }
+        g_emu_zstd_refused += refused;
+    }
+    const bool run_fused = (unread[0] || unread[1]) && (!planned || refused > 0);
+    if (!run_fused) { unread[0] = false; unread[1] = false; }
     const bool two_waves = unread[1] && zstd_kernel_lds_bytes(max_bs, 2) <= 163840;       // (engine.hip: decompress_finish)
     if (!two_waves) { unread[0] = unread[0] || unread[1]; unread[1] = false; }
     for (int kind = 0; kind < 2; kind++) {
         if (!unread[kind]) continue;
         const int nw = kind ? 2 : 1;
-        DecodeArgs za = da;
+        DecodeArgs za = zb;
         za.lds_bytes = zstd_kernel_lds_bytes(max_bs, nw);
         za.done = nullptr;
         za.tune = two_waves ? 1 : 0;
@@ -280,6 +320,35 @@ int emu_zstd_decode(const uint8_t* src, int csize, uint8_t* dst, int cap)
             size_t k = 0;
             while (k < (size_t)rc3[0] && out3[m][k] == out3[2][k]) ++k;
             if (k < (size_t)rc3[0]) fprintf(stderr, "[emu zstd] mode %d differs from mode 2 at byte %zu of %d\n", m, k, rc3[0]);
+        }
+    }
+    // the frame WALKED into a plan (zstd_walk_kernel.h: ops, records, coded literals -- exact-size areas here) and the plan replayed:
+    // the same answer; a plan that does not fit its areas is the one thing that may differ (the kernel then takes the decoder proper)
+    {
+        const int stage_cap = (int)ZSTD_KERNEL_STAGE;
+        std::vector<uint8_t> stage((size_t)stage_cap + 16);
+        std::vector<ZstdWork> w(1);
+        w[0].stage = stage.data() + ((16 - ((uintptr_t)stage.data() & 15)) & 15);
+        w[0].stage_cap = stage_cap;
+        w[0].tail = 1;
+        std::vector<ZstdOp> ops(16);
+        std::vector<uint64_t> recs((size_t)cap / 3 + 8);
+        std::vector<uint8_t> lits((size_t)((cap + 15) & ~15) + 16);
+        w[0].ops = ops.data(); w[0].op_cap = (int)ops.size(); w[0].recs = recs.data(); w[0].rec_cap = (int)recs.size();
+        w[0].lits = lits.data(); w[0].lit_cap = (int)lits.size() & ~15; w[0].stream = 5;
+        w[0].mem_lo = stage.data(); w[0].mem_hi = stage.data() + 8;          // ("this is the kernel": the typed Huffman loop where it applies)
+        const int rw = zstd_decode_frame(in.data(), csize, nullptr, cap, &w[0]);
+        if (rw != ZSTD_WALK_OVERFLOW) {
+            // (a walker may accept what only the output shows to be wrong: the replay must refuse it then)
+            if (rw >= 0) {
+                std::vector<uint8_t> out((size_t)cap, 0);
+                const uint8_t* lo = (const uint8_t*)(((uintptr_t)out.data() + 3) & ~(uintptr_t)3);
+                const uint8_t* hi = (const uint8_t*)(((uintptr_t)out.data() + (size_t)cap) & ~(uintptr_t)3);
+                int next = 0;
+                const int rr = zstd_replay_frame<uint8_t*>(ops.data(), 0, w[0].op_n, 5, recs.data(), w[0].rec_n, out.data(), cap, lo, hi, &next);
+                if ((rr >= 0) != (rc3[0] >= 0)) return -997;
+                if (rr >= 0 && (rr != rc3[0] || next != w[0].op_n || (rr > 0 && memcmp(out.data(), out3[0].data(), (size_t)rr)))) return -996;
+            } else if (rc3[0] >= 0) return -995;
         }
     }
     for (int mode = 1; mode < 3; ++mode)

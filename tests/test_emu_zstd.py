@@ -67,6 +67,28 @@ def test_blosc2_zstd_chunks_decode_through_the_kernels(kat):
         assert out[0].tobytes() == src.tobytes(), name
 
 
+@pytest.fixture(params=["planned", "fused", "plans_overflow"], autouse=True)
+def zstd_read_path(request):
+    """Every test of this file three times: the walk + replay launches (engine.hip: decompress_finish), the fused kernels alone
+    (CIMG_ZSTD_FUSED=1), and plans so small (256 bytes of records, of literals) that most blocks are refused by the walk and decoded
+    by the fused kernels behind the two launches."""
+    E.set_zstd_plan({"planned": -1, "fused": 0, "plans_overflow": 256}[request.param])
+    E.zstd_refused()
+    yield request.param
+    E.set_zstd_plan(-1)
+
+
+def test_plans_that_do_not_fit_are_counted_and_their_blocks_still_decode(kat, zstd_read_path):
+    name = "natural_f32_split"
+    chunk = kat["chunk|" + name]; src = kat["cin|" + name]
+    bs = int(np.frombuffer(chunk[8:12].tobytes(), "<i4")[0])
+    E.zstd_refused()
+    rc, status, out = E.decompress_batch([chunk.tobytes()], [src.size], [bs])
+    assert rc == 0 and status == [0] and out[0].tobytes() == src.tobytes()
+    refused = E.zstd_refused()
+    assert (refused > 0) == (zstd_read_path == "plans_overflow"), (zstd_read_path, refused)
+
+
 def test_split_and_unsplit_zstd_chunks_in_one_batch(kat):
     """Split chunks go to the two-waves-per-block launch, chunks of one stream per block to the one-wave launch (engine.hip:
     decompress_finish; each launch reads its own kind only): one batch with both, and LZ4 chunks between them."""

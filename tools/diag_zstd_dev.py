@@ -7,7 +7,7 @@ sys.path[:0] = [os.path.join(os.getcwd(), "compressed-image_amd"), os.path.join(
 import numpy as np
 import _oracle as O
 from cimg import hip, synth
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if a in ("tiled", "natural", "zero", "random")]
 clevel = int(sys.argv[sys.argv.index("--clevel") + 1]) if "--clevel" in sys.argv else 9
 mib = int(sys.argv[sys.argv.index("--mib") + 1]) if "--mib" in sys.argv else 128
 fams = [a for a in args] or ["tiled", "natural"]
@@ -36,6 +36,11 @@ for fam in fams:
     for _ in range(3): eng.decompress_device(d_comp.ptr, coff, [CHUNK] * nch, [32768] * nch, d_out.ptr, roff, comp_size=cb)
     ms, k = eng.kernel_time(hip.K_DECODE_ZSTD)
     eng.enable_timing(False)
+    parts = []
+    for kid in (hip.K_ZSTD_WALK, hip.K_ZSTD_REPLAY, hip.K_ZSTD_FUSED):
+        pm, pk = eng.kernel_time(kid)
+        if pk: parts.append("%s %.2f ms" % (hip.KERNELS[kid], pm / pk))
+    print("   " + ", ".join(parts))
     print("%s float32 %d MiB, libzstd clevel %d (ratio %.2f, made in %.1f s): cimg_decode_zstd %.2f ms = %.1f GB/s, pixels %s" % (
         fam, mib, clevel, n / float(cb.sum()), t_make, ms / k, n / (ms / k * 1e-3) / 1e9, "bit-exact" if ok else "DIFFER"))
     d_comp.free(); d_out.free()
