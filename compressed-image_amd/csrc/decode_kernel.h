@@ -61,6 +61,8 @@ struct DecodeArgs {
     uint8_t* zplan;
     int64_t zplan_stride;
     int32_t zcap, zarea;
+    int32_t zlanes;           // > 0: walkers leave sequences to cimg_zstd_seq (zstd_seq_kernel.h), which gives this many lanes of a wave a block each
+    int32_t zblocks;          // blocks of the group (cimg_zstd_seq: lane l of workgroup g has block g * zlanes + l of them)
 };
 
 CIMG_HD int round16(int x) { return (x + 15) & ~15; }

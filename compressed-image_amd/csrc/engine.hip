@@ -17,6 +17,7 @@
 #include "deinterleave_kernel.h"
 #include "zstd_kernel.h"
 #include "zstd_walk_kernel.h"
+#include "zstd_seq_kernel.h"
 #include "../../include/cimg_hip.h"
 
 using namespace cimg;
@@ -110,6 +111,13 @@ extern "C" __global__ __launch_bounds__(64) void cimg_zstd_walk(DecodeArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     ZstdWalkBlock blk(a, lds, a.blk_first + (int)blockIdx.x);
     blk.run();
+}
+// the sequences of the blocks' jobs, one LANE per block (zstd_seq_kernel.h)
+extern "C" __global__ __launch_bounds__(64) void cimg_zstd_seq(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    ZstdSeqLanes w(a, lds, (int)blockIdx.x);
+    w.run();
 }
 extern "C" __global__ __launch_bounds__(64) void cimg_zstd_replay(DecodeArgs a)
 {
@@ -227,6 +235,7 @@ struct cimg_engine {
     int zstd_plan_cap = getenv("CIMG_ZSTD_PLAN_CAP") ? atoi(getenv("CIMG_ZSTD_PLAN_CAP")) : 0;   // diagnostic: bytes of records / literals a plan may take (0: the block area)
     int64_t zstd_plan_bytes = getenv("CIMG_ZSTD_PLAN_MIB") ? atoll(getenv("CIMG_ZSTD_PLAN_MIB")) << 20 : 2048ll << 20;   // plans of one pair of launches (larger batches: in groups)
     int zstd_walk_stage = getenv("CIMG_ZSTD_WALK_STAGE") ? atoi(getenv("CIMG_ZSTD_WALK_STAGE")) : 2048;   // bytes of LDS through which a walker reads a frame's sections (measured on 128 MiB of level-22 float32: 8192 = 8 waves a CU 2.51 ms, 4096 = 10 waves 2.45, 2048 = 11 waves 2.28 -- a section that does not fit is read where it lies)
+    int zstd_lanes = getenv("CIMG_ZSTD_LANES") ? atoi(getenv("CIMG_ZSTD_LANES")) : 8;   // blocks a wave of cimg_zstd_seq decodes side by side (0: the walkers decode sequences themselves)
     DevBuf zplan;
     int64_t lean_batches = 0, lean_blocks_skipped = 0, lean_blocks_total = 0;
     uint32_t lean_last_skipped = 1;     // blocks the previous lean batch left over BEYOND the leftover blocks its geometry announced (1: unknown yet -> general kernel enqueued up front)
@@ -247,7 +256,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    int max_dyn_lds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
+    int max_dyn_lds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -415,6 +424,7 @@ const char* cimg_kernel_name(int k)
     case CIMG_K_ZSTD_WALK: return "cimg_zstd_walk";
     case CIMG_K_ZSTD_REPLAY: return "cimg_zstd_replay";
     case CIMG_K_ZSTD_FUSED: return "cimg_decode_zstd_fused";
+    case CIMG_K_ZSTD_SEQ: return "cimg_zstd_seq";
     default: return "?";
     }
 }
@@ -1065,12 +1075,14 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
         } else {
             const int area = zstd_kernel_area(f.max_blocksize);
             const int cap = e->zstd_plan_cap > 0 ? e->zstd_plan_cap : area;
-            const int64_t stride = zstd_plan_stride(cap);
+            const int lanes = std::max(0, std::min(e->zstd_lanes, std::min(64, (e->lds_per_wg - 64) / (int)ZSTD_SEQ_LANE_BYTES)));
+            const int64_t stride = zstd_plan_stride(cap, lanes > 0);
             const int group = (int)std::max<int64_t>(1, std::min<int64_t>(plan.total_blocks, e->zstd_plan_bytes / stride));
             if ((rc = e->reserve(e->zplan, (size_t)group * (size_t)stride))) return rc;
             volatile uint32_t* refused = skipped_host;           // (the lean launch's words have been read: the first one counts refused plans now)
             zb.skipped = (uint32_t*)((uint8_t*)da.status + ((f.st_bytes + 15) & ~(size_t)15));
-            zb.zplan = (uint8_t*)e->zplan.p; zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area;
+            zb.zplan = (uint8_t*)e->zplan.p; zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.zlanes = lanes;
+            if (lanes > 0 && (rc = e->allow_lds(cimg_zstd_seq, 9, zstd_seq_lds_bytes(lanes)))) return rc;
             if ((rc = e->allow_lds(cimg_zstd_walk, 7, zstd_walk_lds_bytes(e->zstd_walk_stage)))) return rc;
             if ((rc = e->allow_lds(cimg_zstd_replay, 8, replay_lds))) return rc;
             for (int g0 = 0; g0 < plan.total_blocks; g0 += group) {
@@ -1079,6 +1091,11 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
                 DecodeArgs wa = zb;
                 wa.blk_first = g0; wa.lds_bytes = zstd_walk_lds_bytes(e->zstd_walk_stage);
                 if ((rc = e->launch(CIMG_K_ZSTD_WALK, cimg_zstd_walk, wa, nb, 64, wa.lds_bytes))) return rc;
+                if (lanes > 0) {
+                    DecodeArgs sa = zb;
+                    sa.blk_first = g0; sa.zblocks = nb; sa.lds_bytes = zstd_seq_lds_bytes(lanes);
+                    if ((rc = e->launch(CIMG_K_ZSTD_SEQ, cimg_zstd_seq, sa, (nb + lanes - 1) / lanes, 64, sa.lds_bytes))) return rc;
+                }
                 DecodeArgs ra = zb;
                 ra.blk_first = g0; ra.lds_bytes = replay_lds;
                 if ((rc = e->launch(CIMG_K_ZSTD_REPLAY, cimg_zstd_replay, ra, nb, 64, ra.lds_bytes))) return rc;

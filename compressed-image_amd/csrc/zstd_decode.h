@@ -16,6 +16,7 @@
 #include "wave.h"
 #include "decode_kernel.h"      // lz_batch_execute
 #include <cstring>
+#include <cstddef>
 #include <type_traits>
 
 namespace cimg {
@@ -41,6 +42,18 @@ struct ZstdOp {
 static_assert(sizeof(ZstdOp) == 32, "ops are read as two 16-byte loads");
 // a sequence: literal length | match length << 21 | offset << 42 (all three at most the output capacity, < 2^21)
 CIMG_HD uint64_t zstd_record(uint32_t ll, uint32_t ml, uint32_t of) { return (uint64_t)ll | ((uint64_t)ml << 21) | ((uint64_t)of << 42); }
+// A walker may leave the sequences of a compressed block undecoded as well (ZstdWork::defer): the block becomes a JOB -- its three
+// FSE tables copied to the plan, where its bit stream lies, where its records go -- and a third kind of launch decodes the jobs of
+// many blocks at once, one LANE per block (zstd_seq_kernel.h).
+struct ZstdSeqJob {
+    uint64_t bs;                               // address of the bit stream (in the chunk)
+    uint32_t bl, nseq, rec;                    // its bytes; the block's sequences; its first record
+    uint32_t tab;                              // byte offset of its tables in the plan's table area: ll[512] ml[512] of[256], 4 bytes an entry
+    uint8_t ll_log, of_log, ml_log, first;     // first: the first compressed block of its frame (the repeat offsets start over: 1, 4, 8)
+    uint32_t pad;
+};
+static_assert(sizeof(ZstdSeqJob) == 32, "jobs are read as two 16-byte loads");
+enum : int { ZSTD_JOB_TABLE_BYTES = 4 * ((1 << ZSTD_FSE_LOG_MAX) + (1 << ZSTD_FSE_LOG_MAX) + (1 << (ZSTD_FSE_LOG_MAX - 1))) };   // 5120
 enum : int { ZSTD_WALK_OVERFLOW = -2000 };     // internal: the plan does not fit its slot -- the block goes to the decoder that needs none
 
 struct ZstdWork {
@@ -70,8 +83,14 @@ struct ZstdWork {
     ZstdOp* ops;
     uint64_t* recs;
     uint8_t* lits;
-    int32_t op_n, op_cap, rec_n, rec_cap, lit_n, lit_cap, stream, pad_;
+    int32_t op_n, op_cap, rec_n, rec_cap, lit_n, lit_cap, stream;
+    int32_t defer;           // 1: sequences are left to the lane decoder (jobs, tabs below)
+    ZstdSeqJob* jobs;
+    uint8_t* tabs;
+    int32_t job_n, job_cap, tab_n, tab_cap, frame_jobs, pad_;
 };
+static_assert(offsetof(ZstdWork, ml) == offsetof(ZstdWork, ll) + 4 * (1 << ZSTD_FSE_LOG_MAX) && offsetof(ZstdWork, of) == offsetof(ZstdWork, ml) + 4 * (1 << ZSTD_FSE_LOG_MAX),
+              "a job's tables are copied in one piece: ll, ml, of");
 
 // ---- bit readers --------------------------------------------------------------------------------------------------
 // bits [off, off + n) of src (LSB-first within bytes), n <= 32; bytes outside [0, size) read as zero
@@ -1193,6 +1212,26 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         }
         const uint8_t* bs = src + pos;
         const int bl = size - pos;
+        if (walk && zstd_field(&w->defer)) {
+            // the block's sequences become a job of the lane decoder: tables to the plan, the bit stream stays where it lies
+            if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
+            const int jn = zstd_field(&w->job_n), tn = zstd_field(&w->tab_n), rn = zstd_field(&w->rec_n);
+            if (jn >= zstd_field(&w->job_cap) || tn + ZSTD_JOB_TABLE_BYTES > zstd_field(&w->tab_cap) || nseq > zstd_field(&w->rec_cap) - rn) return ZSTD_WALK_OVERFLOW;
+            uint8_t* const tdst = reinterpret_cast<uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->tabs))) + tn;
+            const uint8_t* const tsrc = reinterpret_cast<const uint8_t*>(w->ll);
+            for (int i0 = 0; i0 < ZSTD_JOB_TABLE_BYTES; i0 += 1024) { FOR_LANES_W(l) { st128a(tdst + i0 + 16 * l, ld128u(tsrc + i0 + 16 * l)); } }
+            ZstdSeqJob job;
+            job.bs = (uint64_t)reinterpret_cast<uintptr_t>(bs); job.bl = (uint32_t)bl; job.nseq = (uint32_t)nseq; job.rec = (uint32_t)rn; job.tab = (uint32_t)tn;
+            job.ll_log = (uint8_t)zstd_field(&w->ll_log); job.of_log = (uint8_t)zstd_field(&w->of_log); job.ml_log = (uint8_t)zstd_field(&w->ml_log);
+            job.first = zstd_field(&w->frame_jobs) == 0 ? 1 : 0; job.pad = 0;
+            ZstdSeqJob* const jto = reinterpret_cast<ZstdSeqJob*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->jobs))) + jn;
+            FOR_LANES_W(l) { if (l == 0) *jto = job; }
+            FOR_LANES_W(l) { w->job_n = jn + 1; w->tab_n = tn + ZSTD_JOB_TABLE_BYTES; w->rec_n = rn + nseq; w->frame_jobs = 1; }
+            ZstdOp op;
+            op.kind = ZOP_SEQ; op.size = (uint32_t)regen; op.ptr = lit_word; op.nseq = (uint32_t)nseq; op.rec = (uint32_t)rn; op.lit_fill = lit_fill; op.stream = 0;
+            const int erc = zstd_emit(w, op);
+            return erc < 0 ? erc : dpos;                   // (how far the block gets is for the replay to say)
+        }
         int bs_lds = w->tail ? 0 : 1;                      // (a frame staged whole lies in LDS)
         if (bl >= 1 && bl <= stage_cap) { zstd_stage(w->stage, bs, bl); bs = w->stage; bs_lds = 1; }
         if (bl < 1 || zstd_u8(bs, bl - 1) == 0) return ERR_DATA;
@@ -1251,6 +1290,7 @@ CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int c
     pos += fcs_bytes;
     w->have_huf = 0; w->have_tables = 0;
     const bool walk = zstd_walking(w);
+    if (walk) { FOR_LANES_W(l) { w->frame_jobs = 0; } }
     ZstdFrameState fs;
     fs.r0 = 1; fs.r1 = 4; fs.r2 = 8;
     int dpos = 0;
@@ -1286,14 +1326,17 @@ CIMG_DEV int zstd_decode_frame(const uint8_t* src, int size, uint8_t* dst, int c
         if (last) {
             if (checksum) pos += 4;
             if (pos > size) return ERR_DATA;
-            if (fcs >= 0 && fcs != dpos) return ERR_DATA;
+            const bool deferred = walk && zstd_field(&w->defer);
+            if (fcs >= 0 && fcs != dpos && !deferred) return ERR_DATA;
             if (walk) {
                 ZstdOp op;
-                op.kind = ZOP_END; op.size = (uint32_t)dpos; op.ptr = 0; op.nseq = 0; op.rec = 0; op.lit_fill = 0; op.stream = 0;
+                // (a walker that left sequences to the lane decoder does not know how far the frame got: the replay is told what the
+                // frame header promised, or -- no promise -- the capacity, which is what the caller requires of a stream anyway)
+                op.kind = ZOP_END; op.size = (uint32_t)(deferred ? (fcs >= 0 ? (int)fcs : cap) : dpos); op.ptr = 0; op.nseq = 0; op.rec = 0; op.lit_fill = 0; op.stream = 0;
                 const int rc = zstd_emit(w, op);
                 if (rc < 0) return rc;
             }
-            return dpos;
+            return deferred ? cap : dpos;
         }
     }
     return ERR_DATA;

@@ -1,0 +1,204 @@
+// zstd_seq_kernel.h -- the sequences of MANY blocks at once, one lane per block (round 4).
+//
+// Decoding FSE-coded sequences is a serial walk down a bit stream: as wave-uniform scalar code (zstd_decode.h: zstd_sequences) it
+// runs at what a SIMD issues for one wave, about a sequence per 800 cycles and SIMD however many waves share it.  The walk of one
+// block is independent of every other block's, though, and what it needs is small -- three tables (5 KiB), a bit position, three
+// states, three offsets.  cimg_zstd_seq gives every lane of a wave a block of its own: lane l of workgroup g takes the jobs the
+// walker left in the plan of block g * lanes + l (ZstdSeqJob: the block's tables copied to the plan, the bit stream where it lies in
+// the chunk), its tables in the lane's 5 KiB of LDS, its bit stream read through a 128-bit window in registers with the next 64
+// bits requested one step ahead, and writes the 8-byte records cimg_zstd_replay executes.  A wave decodes `lanes` sequences per
+// step instead of one.
+#pragma once
+#include "zstd_walk_kernel.h"
+
+namespace cimg {
+
+// a lane's LDS: its job's tables, and ZSTD_SEQ_STREAM bytes for the job's bit stream -- brought over in one wide copy when it fits
+// (a stream read where it lies costs a trip to global memory per 64 bits, and the wave waits for every lane's)
+enum : int { ZSTD_SEQ_STREAM = 4096, ZSTD_SEQ_PAD = 32, ZSTD_SEQ_LANE_BYTES = ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD + ZSTD_SEQ_STREAM };   // (PAD zero bytes in front of the stream: its window may begin below bit 0)
+CIMG_HD int zstd_seq_lds_bytes(int lanes) { return lanes * ZSTD_SEQ_LANE_BYTES + 64; }
+
+// bits [p, p + 64) of a stream of bl bytes, p a multiple of 8 and any value; bits outside the stream read as zero
+CIMG_DEV uint64_t zstd_window64(const uint8_t* bs, int bl, int p)
+{
+    const int b = p >> 3;
+    uint64_t v = 0;
+    if (b >= 0 && b + 8 <= bl) { memcpy(&v, bs + b, 8); return v; }
+    for (int k = 0; k < 8; k++) { const int i = b + k; if (i >= 0 && i < bl) v |= (uint64_t)bs[i] << (8 * k); }
+    return v;
+}
+
+struct ZstdSeqLanes {
+    const DecodeArgs& a;
+    uint8_t* lds;
+    int g;
+    CIMG_DEV ZstdSeqLanes(const DecodeArgs& a_, uint8_t* lds_, int g_) : a(a_), lds(lds_), g(g_) {}
+
+    CIMG_DEV void run()
+    {
+        const int lanes = a.zlanes;
+        LV<uint8_t*> slot;                 // the lane's plan
+        LV<int> njobs, job_i, rem, err;
+        FOR_LANES(l) {
+            const int k = g * lanes + l;   // block of the group
+            const bool mine = l < lanes && k < a.zblocks;
+            slot[l] = a.zplan + (int64_t)(mine ? k : 0) * a.zplan_stride;
+            const int32_t* const head = reinterpret_cast<const int32_t*>(slot[l]);
+            njobs[l] = (mine && head[0] == ZPLAN_READY) ? head[3] : 0;
+            if (njobs[l] < 0 || njobs[l] > ZSTD_PLAN_JOBS) njobs[l] = 0;
+            job_i[l] = 0; rem[l] = 0; err[l] = 0;
+        }
+        // per lane: the job being decoded
+        LV<const uint8_t*> bs;
+        LV<uint64_t*> rec;
+        LV<int> bl, off, lo, sl, so, sm, r0, r1, r2, llm, ofm, mlm;
+        LV<uint64_t> c0, c1;               // bits [lo, lo + 64), [lo + 64, lo + 128) of the stream: read anew for every sequence
+        LV<bool> inlds;                    // the stream lies in the lane's LDS (zero bytes in front of it)
+        FOR_LANES(l) { bs[l] = nullptr; rec[l] = nullptr; bl[l] = 0; off[l] = 0; lo[l] = 0; sl[l] = so[l] = sm[l] = 0; r0[l] = 1; r1[l] = 4; r2[l] = 8;
+                       llm[l] = ofm[l] = mlm[l] = 0; c0[l] = c1[l] = 0; inlds[l] = false; }
+        const int cap = (a.zcap + 15) & ~15;
+        for (int guard = 0; guard < (1 << 30); ++guard) {
+            // ---- lanes between jobs: the next job's tables into the lane's LDS, its reader and states set up
+            LV<bool> want;
+            FOR_LANES(l) { want[l] = rem[l] == 0 && err[l] == 0 && job_i[l] < njobs[l]; }
+            uint64_t need = ballot(want);
+            while (need) {
+                const int t = ctz64(need);
+                need &= need - 1;
+                const uint8_t* const sl_t = a.zplan + (int64_t)(g * lanes + t) * a.zplan_stride;          // (a lane that wants a job has a block)
+                const int ji = uni(readlane(job_i, t));
+                const uint32_t* const jq = reinterpret_cast<const uint32_t*>(sl_t + ZSTD_PLAN_JOBS_AT + 32 * ji);
+                const uint32_t tab = uni(jq[5]);
+                int bad = 0;
+                if (tab > (uint32_t)(ZSTD_PLAN_TABLE_BYTES - ZSTD_JOB_TABLE_BYTES) || (tab & 15)) bad = 1;
+                if (!bad) wave_copy_g2l(sl_t + ZSTD_PLAN_HEAD + 2 * (int64_t)cap + tab, lds, t * ZSTD_SEQ_LANE_BYTES, ZSTD_JOB_TABLE_BYTES);
+                // the bit stream beside them when it fits: whole 16-byte units wide, the last bytes one by one
+                const uint32_t jbl = uni(jq[2]);
+                const uint8_t* const jbs = reinterpret_cast<const uint8_t*>((uintptr_t)((uint64_t)uni(jq[0]) | ((uint64_t)uni(jq[1]) << 32)));
+                const bool staged = !bad && jbl >= 1 && jbl <= (uint32_t)ZSTD_SEQ_STREAM;
+                if (staged) {
+                    const int at = t * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD;
+                    FOR_LANES_W(l) { if (l < ZSTD_SEQ_PAD) lds[at - ZSTD_SEQ_PAD + l] = 0; }
+                    wave_copy_g2l(jbs, lds, at, (int)(jbl & ~15u));
+                    FOR_LANES_W(l) { if (l < (int)(jbl & 15u)) lds[at + (jbl & ~15u) + l] = jbs[(jbl & ~15u) + l]; }
+                }
+                FOR_LANES(l) {
+                    if (l == t) {
+                        const ZstdSeqJob* const job = reinterpret_cast<const ZstdSeqJob*>(slot[l] + ZSTD_PLAN_JOBS_AT) + job_i[l];
+                        const ZstdSeqJob j = *job;
+                        job_i[l] += 1;
+                        const int nrecs = cap >> 3;
+                        if (bad || j.bl < 1 || j.bl > (1u << 24) || j.nseq < 1 || j.nseq > (uint32_t)nrecs || j.rec > (uint32_t)nrecs - j.nseq || j.ll_log > 9 || j.of_log > 8 || j.ml_log > 9) err[l] = ERR_DATA;
+                        else {
+                            bs[l] = staged ? lds + l * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD : reinterpret_cast<const uint8_t*>((uintptr_t)j.bs);
+                            inlds[l] = staged;
+                            bl[l] = (int)j.bl;
+                            rec[l] = reinterpret_cast<uint64_t*>(slot[l] + ZSTD_PLAN_HEAD) + j.rec;
+                            rem[l] = (int)j.nseq;
+                            llm[l] = (1 << j.ll_log) - 1; ofm[l] = (1 << j.of_log) - 1; mlm[l] = (1 << j.ml_log) - 1;
+                            if (j.first) { r0[l] = 1; r1[l] = 4; r2[l] = 8; }
+                            const int last = bs[l][bl[l] - 1];
+                            if (last == 0) { err[l] = ERR_DATA; rem[l] = 0; }
+                            else {
+                                off[l] = 8 * bl[l] - (8 - zstd_highbit((uint32_t)last));
+                                lo[l] = 8 * bl[l] - 128;
+                                c1[l] = zstd_window64(bs[l], bl[l], lo[l] + 64);
+                                c0[l] = zstd_window64(bs[l], bl[l], lo[l]);
+                                // the three initial states: literal lengths, offsets, match lengths (at most 9 + 8 + 9 bits: inside the window)
+                                sl[l] = (int)take(c0[l], c1[l], lo[l], off[l], j.ll_log);
+                                so[l] = (int)take(c0[l], c1[l], lo[l], off[l], j.of_log);
+                                sm[l] = (int)take(c0[l], c1[l], lo[l], off[l], j.ml_log);
+                            }
+                        }
+                    }
+                }
+            }
+            LV<bool> act;
+            FOR_LANES(l) { act[l] = rem[l] > 0 && err[l] == 0; }
+            if (!ballot(act)) break;
+            // ---- one sequence per lane and step, until a lane is through with its job
+            for (;;) {
+                LV<bool> through;
+                FOR_LANES(l) {
+                    through[l] = false;
+                    if (rem[l] > 0 && err[l] == 0) {
+                        // The window: the 128 bits that end with the byte the reader stands in -- a sequence takes at most 31 + 16 + 16
+                        // bits of lengths and offset and 26 bits of states, 89 of the 121 it can count on.  Read anew for every sequence
+                        // (two LDS reads beside the three of the table entries, no bookkeeping); below bit 0 lie zero bytes.
+                        {
+                            const int B = ((off[l] + 7) >> 3) - 16;
+                            lo[l] = 8 * B;
+                            if (inlds[l]) {
+                                cimg_lds_cu8p const q = CIMG_AS_LDS_CU8(lds + l * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD) + (B < -ZSTD_SEQ_PAD ? -ZSTD_SEQ_PAD : B);
+                                uint64_t lo64, hi64;
+                                __builtin_memcpy(&lo64, q, 8);
+                                __builtin_memcpy(&hi64, q + 8, 8);
+                                c0[l] = lo64; c1[l] = hi64;
+                            } else {
+                                c0[l] = zstd_window64(bs[l], bl[l], lo[l]);
+                                c1[l] = zstd_window64(bs[l], bl[l], lo[l] + 64);
+                            }
+                        }
+                        cimg_lds_cu32p const T = CIMG_AS_LDS_CU32(lds + l * ZSTD_SEQ_LANE_BYTES);
+                        const uint32_t pl = T[sl[l] & llm[l]], pm = T[512 + (sm[l] & mlm[l])], po = T[1024 + (so[l] & ofm[l])];
+                        const int ls = (int)(pl & 0xFF), lnb = (int)((pl >> 8) & 0xFF), lbase = (int)(pl >> 16);
+                        const int os = (int)(po & 0xFF), onb = (int)((po >> 8) & 0xFF), obase = (int)(po >> 16);
+                        const int ms = (int)(pm & 0xFF), mnb = (int)((pm >> 8) & 0xFF), mbase = (int)(pm >> 16);
+                        if (os > 31 || ls > 35 || ms > 52 || lnb > 9 || onb > 8 || mnb > 9) { err[l] = ERR_DATA; }
+                        else {
+                            const uint32_t xo = take(c0[l], c1[l], lo[l], off[l], os);
+                            // (most sequences of an image have a literal length below 16 and a match length below 35: coded directly)
+                            int llen = ls, mlen = ms + 3;
+                            if (ls >= 16 || ms >= 32) {
+                                const int xb = zstd_ml_bits(ms), xc = zstd_ll_bits(ls);
+                                const uint32_t xm = take(c0[l], c1[l], lo[l], off[l], xb);
+                                const uint32_t xl = take(c0[l], c1[l], lo[l], off[l], xc);
+                                llen = zstd_ll_base(ls) + (int)xl; mlen = zstd_ml_base(ms) + (int)xm;
+                            }
+                            const uint32_t ov = (1u << os) + xo;
+                            if (rem[l] > 1) {
+                                const uint32_t V = take(c0[l], c1[l], lo[l], off[l], lnb + mnb + onb);
+                                so[l] = obase + (int)(V & ((1u << onb) - 1));
+                                sm[l] = mbase + (int)((V >> onb) & ((1u << mnb) - 1));
+                                sl[l] = lbase + (int)(V >> (onb + mnb));
+                            }
+                            int offset;
+                            if (ov > 3) { offset = (int)(ov - 3); r2[l] = r1[l]; r1[l] = r0[l]; r0[l] = offset; }
+                            else {
+                                const int idx = (int)ov + (llen == 0 ? 1 : 0);
+                                if (idx == 1) offset = r0[l];
+                                else if (idx == 2) { offset = r1[l]; r1[l] = r0[l]; r0[l] = offset; }
+                                else { offset = idx == 3 ? r2[l] : r0[l] - 1; r2[l] = r1[l]; r1[l] = r0[l]; r0[l] = offset; }
+                            }
+                            if (off[l] < 0 || offset <= 0 || offset >= (1 << 22) || llen >= (1 << 21) || mlen >= (1 << 21)) err[l] = ERR_DATA;
+                            else {
+                                *rec[l] = zstd_record((uint32_t)llen, (uint32_t)mlen, (uint32_t)offset);
+                                rec[l] += 1;
+                                rem[l] -= 1;
+                                if (rem[l] == 0 && off[l] != 0) err[l] = ERR_DATA;       // a stream ends at its first bit
+                            }
+                        }
+                        through[l] = rem[l] == 0 || err[l] != 0;
+                    }
+                }
+                if (ballot(through)) break;
+            }
+        }
+        // a lane that met damage says so in its block's plan (the replay reports it)
+        FOR_LANES_W(l) {
+            if (err[l] != 0) { int32_t* const head = reinterpret_cast<int32_t*>(slot[l]); head[0] = err[l]; }
+        }
+    }
+
+    // n bits (n <= 32) below position `off` of the 128-bit window c1:c0 = bits [lo, lo + 128); off moves down
+    static CIMG_DEV uint32_t take(uint64_t c0, uint64_t c1, int lo, int& off, int n)
+    {
+        off -= n;
+        const int s = off - lo;                                // >= 0 while the window rule of the loop holds; a damaged stream may break it
+        if (n <= 0 || s < 0 || s >= 128) return 0;
+        const uint64_t v = s >= 64 ? (c1 >> (s - 64)) : (s ? (c0 >> s) | (c1 << (64 - s)) : c0);
+        return (uint32_t)v & (uint32_t)((1ull << n) - 1);
+    }
+};
+
+}  // namespace cimg

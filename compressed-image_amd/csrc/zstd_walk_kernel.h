@@ -15,11 +15,12 @@
 
 namespace cimg {
 
-enum : int { ZSTD_PLAN_OPS = 62, ZSTD_PLAN_HEAD = 2048 };
+enum : int { ZSTD_PLAN_OPS = 62, ZSTD_PLAN_JOBS_AT = 2048, ZSTD_PLAN_JOBS = 32, ZSTD_PLAN_HEAD = 3072, ZSTD_PLAN_TABLES = 4, ZSTD_PLAN_TABLE_BYTES = ZSTD_PLAN_TABLES * ZSTD_JOB_TABLE_BYTES };
 enum : int { ZPLAN_NOT_OURS = 0, ZPLAN_READY = 1, ZPLAN_FALLBACK = 2 };          // a plan's first word; negative: the block's error code
-static_assert(16 + ZSTD_PLAN_OPS * sizeof(ZstdOp) <= ZSTD_PLAN_HEAD, "status, counts and the ops in the head of a slot");
-// a slot: head (status, ops, records, 0 | the ops), `cap` bytes of records, `cap` bytes of literals
-CIMG_HD int64_t zstd_plan_stride(int cap) { return ZSTD_PLAN_HEAD + 2 * (int64_t)((cap + 15) & ~15); }
+static_assert(16 + ZSTD_PLAN_OPS * sizeof(ZstdOp) <= ZSTD_PLAN_JOBS_AT && ZSTD_PLAN_JOBS_AT + ZSTD_PLAN_JOBS * sizeof(ZstdSeqJob) <= ZSTD_PLAN_HEAD, "status, counts, ops and jobs in the head of a slot");
+// a slot: head (status, ops, records, jobs | the ops | the jobs), `cap` bytes of records, `cap` bytes of literals, and -- jobs for the
+// lane decoder -- room for the tables of ZSTD_PLAN_TABLES compressed blocks
+CIMG_HD int64_t zstd_plan_stride(int cap, bool jobs) { return ZSTD_PLAN_HEAD + 2 * (int64_t)((cap + 15) & ~15) + (jobs ? ZSTD_PLAN_TABLE_BYTES : 0); }
 CIMG_HD int zstd_walk_lds_bytes(int stage = ZSTD_KERNEL_STAGE) { return ((stage + 15) & ~15) + zstd_work_bytes() + 64; }
 CIMG_HD int zstd_replay_lds_bytes(int max_blocksize) { return zstd_kernel_area(max_blocksize) + 64; }
 
@@ -29,9 +30,9 @@ struct ZstdWalkBlock {
     int b;
     CIMG_DEV ZstdWalkBlock(const DecodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
 
-    CIMG_DEV void say(int32_t* head, int status, int nops, int nrecs)
+    CIMG_DEV void say(int32_t* head, int status, int nops, int nrecs, int njobs = 0)
     {
-        FOR_LANES_W(l) { if (l == 0) { head[1] = nops; head[2] = nrecs; head[3] = 0; head[0] = status; } }
+        FOR_LANES_W(l) { if (l == 0) { head[1] = nops; head[2] = nrecs; head[3] = njobs; head[0] = status; } }
     }
     CIMG_DEV void run()
     {
@@ -52,6 +53,9 @@ struct ZstdWalkBlock {
             w->recs = reinterpret_cast<uint64_t*>(slot + ZSTD_PLAN_HEAD); w->rec_cap = cap >> 3; w->rec_n = 0;
             w->lits = slot + ZSTD_PLAN_HEAD + cap; w->lit_cap = cap; w->lit_n = 0;
             w->stream = 0;
+            w->defer = a.zlanes > 0 ? 1 : 0;
+            w->jobs = reinterpret_cast<ZstdSeqJob*>(slot + ZSTD_PLAN_JOBS_AT); w->job_cap = ZSTD_PLAN_JOBS; w->job_n = 0;
+            w->tabs = slot + ZSTD_PLAN_HEAD + 2 * (int64_t)cap; w->tab_cap = a.zlanes > 0 ? ZSTD_PLAN_TABLE_BYTES : 0; w->tab_n = 0; w->frame_jobs = 0;
         }
         int pos = g.bstart;
         for (int s = 0; s < g.ns; s++) {
@@ -72,7 +76,7 @@ struct ZstdWalkBlock {
             } else if (cs > g.neblock) { say(head, ERR_DATA, 0, 0); return; }
             pos += payload;                                      // (run tokens and stored streams: the replay reads them in the chunk)
         }
-        say(head, ZPLAN_READY, zstd_field(&w->op_n), zstd_field(&w->rec_n));
+        say(head, ZPLAN_READY, zstd_field(&w->op_n), zstd_field(&w->rec_n), zstd_field(&w->job_n));
     }
 };
 

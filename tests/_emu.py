@@ -82,6 +82,11 @@ def set_zstd_plan(cap):
     lib().emu_set_zstd_plan(int(cap))
 
 
+def set_zstd_lanes(n):
+    """Blocks a wave of the lane decoder (cimg_zstd_seq) takes side by side; 0: the walkers decode the sequences themselves."""
+    lib().emu_set_zstd_lanes(int(n))
+
+
 def zstd_refused():
     """Blocks whose plan did not fit its slot since the last call."""
     lib().emu_zstd_refused.restype = C.c_long

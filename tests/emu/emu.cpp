@@ -6,6 +6,7 @@
 #include "plan.h"
 #include "zstd_kernel.h"
 #include "zstd_walk_kernel.h"
+#include "zstd_seq_kernel.h"
 #include "deinterleave_kernel.h"
 #include "assemble_kernel.h"
 #include "blosclz_kernel.h"
@@ -28,6 +29,7 @@ namespace cimg { long g_emu_dec_par = 0, g_emu_dec_serial = 0, g_emu_dec_batches
 using namespace cimg;
 static int g_emu_zstd_plan_cap = -1;    // -1: the block area (the engine's default); 0: no plans (fused kernels only); n: n bytes of records / literals a plan
 static long g_emu_zstd_refused = 0;
+static int g_emu_zstd_lanes = 8;         // blocks a wave of the lane decoder takes (0: the walkers decode sequences themselves)
 static int g_emu_block_items = 1;     // tests also run the one-item-per-plane form
 
 extern "C" {
@@ -126,6 +128,7 @@ int g_emu_lean = 1;            // tests switch the lean kernel off to cover the 
 long g_emu_lean_blocks = 0;    // blocks the lean kernel produced since the last emu_stats reset
 extern "C" void emu_set_lean(int on) { g_emu_lean = on; }
 extern "C" void emu_set_zstd_plan(int cap) { g_emu_zstd_plan_cap = cap; }
+extern "C" void emu_set_zstd_lanes(int n) { g_emu_zstd_lanes = n; }
 extern "C" long emu_zstd_refused() { const long r = g_emu_zstd_refused; g_emu_zstd_refused = 0; return r; }
 extern "C" long emu_lean_blocks(void) { const long n = g_emu_lean_blocks; g_emu_lean_blocks = 0; return n; }
 
@@ -189,10 +192,11 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     if (planned) {
         const int area = zstd_kernel_area(max_bs);
         const int cap = g_emu_zstd_plan_cap > 0 ? g_emu_zstd_plan_cap : area;
-        const int64_t stride = zstd_plan_stride(cap);
+        const int lanes = g_emu_zstd_lanes;
+        const int64_t stride = zstd_plan_stride(cap, lanes > 0);
         zplan.assign((size_t)plan.total_blocks * (size_t)stride, 0xCD);
         zb.skipped = &refused;
-        zb.zplan = zplan.data(); zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.blk_first = 0;
+        zb.zplan = zplan.data(); zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.blk_first = 0; zb.zlanes = lanes; zb.zblocks = plan.total_blocks;
         DecodeArgs wa = zb;
         wa.lds_bytes = zstd_walk_lds_bytes();
         std::vector<uint8_t> wl((size_t)wa.lds_bytes + EMU_LDS_SLACK);
@@ -200,6 +204,16 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
             memset(wl.data(), 0xCD, wl.size());
             ZstdWalkBlock blk(wa, wl.data(), b);
             blk.run();
+        }
+        if (lanes > 0) {
+            DecodeArgs sa = zb;
+            sa.lds_bytes = zstd_seq_lds_bytes(lanes);
+            std::vector<uint8_t> sl((size_t)sa.lds_bytes);
+            for (int g = 0; g * lanes < plan.total_blocks; g++) {
+                memset(sl.data(), 0xCD, sl.size());
+                ZstdSeqLanes w(sa, sl.data(), g);
+                w.run();
+            }
         }
         DecodeArgs ra = zb;
         ra.lds_bytes = zstd_replay_lds_bytes(max_bs);

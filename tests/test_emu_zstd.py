@@ -67,15 +67,18 @@ def test_blosc2_zstd_chunks_decode_through_the_kernels(kat):
         assert out[0].tobytes() == src.tobytes(), name
 
 
-@pytest.fixture(params=["planned", "fused", "plans_overflow"], autouse=True)
+@pytest.fixture(params=["planned", "planned_3_lanes", "walkers_decode_sequences", "fused", "plans_overflow"], autouse=True)
 def zstd_read_path(request):
-    """Every test of this file three times: the walk + replay launches (engine.hip: decompress_finish), the fused kernels alone
-    (CIMG_ZSTD_FUSED=1), and plans so small (256 bytes of records, of literals) that most blocks are refused by the walk and decoded
-    by the fused kernels behind the two launches."""
-    E.set_zstd_plan({"planned": -1, "fused": 0, "plans_overflow": 256}[request.param])
+    """Every test of this file in every form of the read path: the walk + lane decoder + replay launches (engine.hip:
+    decompress_finish; eight blocks a wave, and three -- workgroups that end inside a chunk), the walkers decoding the sequences
+    themselves (CIMG_ZSTD_LANES=0), the fused kernels alone (CIMG_ZSTD_FUSED=1), and plans so small (256 bytes of records, of
+    literals) that most blocks are refused by the walk and decoded by the fused kernels behind the launches."""
+    E.set_zstd_plan({"fused": 0, "plans_overflow": 256}.get(request.param, -1))
+    E.set_zstd_lanes({"planned_3_lanes": 3, "walkers_decode_sequences": 0}.get(request.param, 8))
     E.zstd_refused()
     yield request.param
     E.set_zstd_plan(-1)
+    E.set_zstd_lanes(8)
 
 
 def test_plans_that_do_not_fit_are_counted_and_their_blocks_still_decode(kat, zstd_read_path):
