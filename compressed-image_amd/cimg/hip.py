@@ -12,14 +12,14 @@ import numpy as np
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("CIMG_LIB") or os.path.join(_PKG, "libcimg_hip.so")   # CIMG_LIB: diagnostic builds
 
-K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE, K_DEINTERLEAVE, K_DECODE_ZSTD, K_ENCODE_ZSTD, K_ZSTD_WALK, K_ZSTD_REPLAY, K_ZSTD_FUSED, K_ZSTD_SEQ = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+K_ENCODE, K_LAYOUT, K_EMIT, K_DECODE, K_DEINTERLEAVE, K_DECODE_ZSTD, K_ENCODE_ZSTD, K_ZSTD_WALK, K_ZSTD_REPLAY, K_ZSTD_FUSED, K_ZSTD_SEQ, K_ZSTD_LIT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 # names by timing id (cimg_kernel_name).  K_ENCODE times whichever of cimg_encode_streams / _blosclz the codec selects; K_DECODE
 # times the pair cimg_decode_lean + cimg_decode_blocks (the second only runs for blocks the first left): bench.py reports it under
 # the kernel that did the work
 KERNELS = ("cimg_encode_streams", "cimg_layout_chunks", "cimg_emit_blocks", "cimg_decode_blocks", "cimg_deinterleave",
-           "cimg_decode_zstd", "cimg_encode_streams_zstd", "cimg_zstd_walk", "cimg_zstd_replay", "cimg_decode_zstd_fused", "cimg_zstd_seq")
-# (K_DECODE_ZSTD times the zstd read path of a batch as a whole -- cimg_zstd_walk + cimg_zstd_seq + cimg_zstd_replay, and
-# cimg_decode_zstd behind them for blocks the walk refused; the last four ids time those launches one by one)
+           "cimg_decode_zstd", "cimg_encode_streams_zstd", "cimg_zstd_walk", "cimg_zstd_replay", "cimg_decode_zstd_fused", "cimg_zstd_seq", "cimg_zstd_lit")
+# (K_DECODE_ZSTD times the zstd read path of a batch as a whole -- cimg_zstd_walk + cimg_zstd_lit + cimg_zstd_seq + cimg_zstd_replay, and
+# cimg_decode_zstd behind them for blocks the walk refused; the last five ids time those launches one by one)
 BLOSCLZ, LZ4, LZ4HC, ZLIB, ZSTD = 0, 1, 2, 4, 5
 NOFILTER, SHUFFLE, BITSHUFFLE = 0, 1, 2
 MAX_OVERHEAD = 32

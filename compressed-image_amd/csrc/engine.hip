@@ -18,6 +18,7 @@
 #include "zstd_kernel.h"
 #include "zstd_walk_kernel.h"
 #include "zstd_seq_kernel.h"
+#include "zstd_lit_kernel.h"
 #include "../../include/cimg_hip.h"
 
 using namespace cimg;
@@ -111,6 +112,13 @@ extern "C" __global__ __launch_bounds__(64) void cimg_zstd_walk(DecodeArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     ZstdWalkBlock blk(a, lds, a.blk_first + (int)blockIdx.x);
     blk.run();
+}
+// the Huffman-coded literals of the blocks' jobs, one lane per stream (zstd_lit_kernel.h)
+extern "C" __global__ __launch_bounds__(64) void cimg_zstd_lit(DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    ZstdLitLanes w(a, lds, (int)blockIdx.x);
+    w.run();
 }
 // the sequences of the blocks' jobs, one LANE per block (zstd_seq_kernel.h)
 extern "C" __global__ __launch_bounds__(64) void cimg_zstd_seq(DecodeArgs a)
@@ -256,7 +264,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    int max_dyn_lds[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
+    int max_dyn_lds[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -425,6 +433,7 @@ const char* cimg_kernel_name(int k)
     case CIMG_K_ZSTD_REPLAY: return "cimg_zstd_replay";
     case CIMG_K_ZSTD_FUSED: return "cimg_decode_zstd_fused";
     case CIMG_K_ZSTD_SEQ: return "cimg_zstd_seq";
+    case CIMG_K_ZSTD_LIT: return "cimg_zstd_lit";
     default: return "?";
     }
 }
@@ -1075,7 +1084,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
         } else {
             const int area = zstd_kernel_area(f.max_blocksize);
             const int cap = e->zstd_plan_cap > 0 ? e->zstd_plan_cap : area;
-            const int lanes = std::max(0, std::min(e->zstd_lanes, std::min(64, (e->lds_per_wg - 64) / (int)ZSTD_SEQ_LANE_BYTES)));
+            const int lanes = std::max(0, std::min(e->zstd_lanes, std::min(64, (e->lds_per_wg - 64 - (int)ZSTD_SEQ_CODES_BYTES) / (int)ZSTD_SEQ_LANE_BYTES)));
             const int64_t stride = zstd_plan_stride(cap, lanes > 0);
             const int group = (int)std::max<int64_t>(1, std::min<int64_t>(plan.total_blocks, e->zstd_plan_bytes / stride));
             if ((rc = e->reserve(e->zplan, (size_t)group * (size_t)stride))) return rc;
@@ -1083,6 +1092,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
             zb.skipped = (uint32_t*)((uint8_t*)da.status + ((f.st_bytes + 15) & ~(size_t)15));
             zb.zplan = (uint8_t*)e->zplan.p; zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.zlanes = lanes;
             if (lanes > 0 && (rc = e->allow_lds(cimg_zstd_seq, 9, zstd_seq_lds_bytes(lanes)))) return rc;
+            if (lanes > 0 && (rc = e->allow_lds(cimg_zstd_lit, 10, zstd_lit_lds_bytes()))) return rc;
             if ((rc = e->allow_lds(cimg_zstd_walk, 7, zstd_walk_lds_bytes(e->zstd_walk_stage)))) return rc;
             if ((rc = e->allow_lds(cimg_zstd_replay, 8, replay_lds))) return rc;
             for (int g0 = 0; g0 < plan.total_blocks; g0 += group) {
@@ -1094,7 +1104,18 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
                 if (lanes > 0) {
                     DecodeArgs sa = zb;
                     sa.blk_first = g0; sa.zblocks = nb; sa.lds_bytes = zstd_seq_lds_bytes(lanes);
+                    DecodeArgs la = sa;
+                    la.lds_bytes = zstd_lit_lds_bytes();
+                    // (literals and sequences of a block are independent of each other: the two launches side by side -- the side
+                    // stream follows the main one up to the walk and is joined in front of the replay)
+                    const bool beside = !e->no_side;
+                    if (beside && (rc = e->side_follows_stream())) return rc;
+                    if ((rc = e->launch(CIMG_K_ZSTD_LIT, cimg_zstd_lit, la, (nb + ZSTD_LIT_BLOCKS - 1) / ZSTD_LIT_BLOCKS, 64, la.lds_bytes, beside ? e->s_side : e->stream))) return rc;
                     if ((rc = e->launch(CIMG_K_ZSTD_SEQ, cimg_zstd_seq, sa, (nb + lanes - 1) / lanes, 64, sa.lds_bytes))) return rc;
+                    if (beside) {
+                        if ((rc = e->hip(hipEventRecord(e->ev_side_done, e->s_side), "event record"))) return rc;
+                        if ((rc = e->hip(hipStreamWaitEvent(e->stream, e->ev_side_done, 0), "stream wait"))) return rc;
+                    }
                 }
                 DecodeArgs ra = zb;
                 ra.blk_first = g0; ra.lds_bytes = replay_lds;

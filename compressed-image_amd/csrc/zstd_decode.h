@@ -53,6 +53,18 @@ struct ZstdSeqJob {
     uint32_t pad;
 };
 static_assert(sizeof(ZstdSeqJob) == 32, "jobs are read as two 16-byte loads");
+// ... and the Huffman-coded literals of a block likewise (zstd_lit_kernel.h: one lane per STREAM, sixteen blocks a wave): the
+// decoding table copied to the plan, the streams where they lie in the chunk, the literals' place in the plan's literal area.
+struct ZstdLitJob {
+    uint64_t src;                              // address of the streams: the jump table of a 4-stream section first
+    uint32_t lsz, regen;                       // bytes at src; literals to regenerate
+    uint32_t out;                              // their place in the plan's literal area
+    uint32_t tab;                              // byte offset of the decoding table in the plan's table area: 2^log entries, symbol | code length << 8
+    uint32_t log, streams;                     // table log (<= 11); 1 or 4 streams
+    uint32_t pad[8];
+};
+static_assert(sizeof(ZstdLitJob) == 64, "literal jobs are read as four 16-byte loads");
+enum : int { ZSTD_HUF_TABLE_BYTES = 2 << ZSTD_HUF_LOG_MAX };   // 4096
 enum : int { ZSTD_JOB_TABLE_BYTES = 4 * ((1 << ZSTD_FSE_LOG_MAX) + (1 << ZSTD_FSE_LOG_MAX) + (1 << (ZSTD_FSE_LOG_MAX - 1))) };   // 5120
 enum : int { ZSTD_WALK_OVERFLOW = -2000 };     // internal: the plan does not fit its slot -- the block goes to the decoder that needs none
 
@@ -87,8 +99,11 @@ struct ZstdWork {
     int32_t defer;           // 1: sequences are left to the lane decoder (jobs, tabs below)
     ZstdSeqJob* jobs;
     uint8_t* tabs;
-    int32_t job_n, job_cap, tab_n, tab_cap, frame_jobs, pad_;
+    int32_t job_n, job_cap, tab_n, tab_cap, frame_jobs, huf_tab;    // huf_tab: where the current Huffman table lies in the plan (treeless blocks use it again)
+    ZstdLitJob* litjobs;
+    int32_t litjob_n, litjob_cap;
 };
+static_assert(offsetof(ZstdWork, huf) == 0, "the Huffman table is copied from the start of the work area");
 static_assert(offsetof(ZstdWork, ml) == offsetof(ZstdWork, ll) + 4 * (1 << ZSTD_FSE_LOG_MAX) && offsetof(ZstdWork, of) == offsetof(ZstdWork, ml) + 4 * (1 << ZSTD_FSE_LOG_MAX),
               "a job's tables are copied in one piece: ll, ml, of");
 
@@ -1137,8 +1152,34 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
 #endif
             if (t < 0) return t;
             ls += t; lsz -= t;
+            if (walk && zstd_field(&w->defer)) {
+                // (the lane decoder of literals reads this table from the plan)
+                const int tn = zstd_field(&w->tab_n);
+                if (tn + ZSTD_HUF_TABLE_BYTES > zstd_field(&w->tab_cap)) return ZSTD_WALK_OVERFLOW;
+                uint8_t* const tdst = reinterpret_cast<uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->tabs))) + tn;
+                const uint8_t* const tsrc = reinterpret_cast<const uint8_t*>(w->huf);
+                for (int i0 = 0; i0 < ZSTD_HUF_TABLE_BYTES; i0 += 1024) { FOR_LANES_W(l) { st128a(tdst + i0 + 16 * l, ld128u(tsrc + i0 + 16 * l)); } }
+                FOR_LANES_W(l) { w->huf_tab = tn; w->tab_n = tn + ZSTD_HUF_TABLE_BYTES; }
+            }
         } else if (!w->have_huf) return ERR_DATA;
-        if (streams == 1) {
+        if (walk && zstd_field(&w->defer)) {
+            // the block's literals become a job of the lane decoder: where the streams lie in the CHUNK (not in the stage)
+            const int jn = zstd_field(&w->litjob_n);
+            if (jn >= zstd_field(&w->litjob_cap)) return ZSTD_WALK_OVERFLOW;
+            const int consumed = comp - lsz;                   // the tree description
+            ZstdLitJob job;
+            memset(&job, 0, sizeof(job));
+            job.src = (uint64_t)reinterpret_cast<uintptr_t>(src + pos + consumed); job.lsz = (uint32_t)lsz; job.regen = (uint32_t)regen;
+            job.out = (uint32_t)(litbuf - reinterpret_cast<uint8_t*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->lits))));
+            job.tab = (uint32_t)zstd_field(&w->huf_tab); job.log = (uint32_t)zstd_field(&w->huf_log); job.streams = (uint32_t)streams;
+            if (streams == 4) {
+                if (lsz < 6) return ERR_DATA;
+                if (3 * ((regen + 3) / 4) > regen) return ERR_DATA;
+            } else if (lsz < 1) return ERR_DATA;
+            ZstdLitJob* const jto = reinterpret_cast<ZstdLitJob*>(uni64((int64_t)reinterpret_cast<uintptr_t>(w->litjobs))) + jn;
+            FOR_LANES_W(l) { if (l == 0) *jto = job; }
+            FOR_LANES_W(l) { w->litjob_n = jn + 1; }
+        } else if (streams == 1) {
             const int rc = zstd_huf_stream(ls, lsz, litbuf, regen, w);
             if (rc < 0) return rc;
         } else {

@@ -16,7 +16,9 @@ namespace cimg {
 // a lane's LDS: its job's tables, and ZSTD_SEQ_STREAM bytes for the job's bit stream -- brought over in one wide copy when it fits
 // (a stream read where it lies costs a trip to global memory per 64 bits, and the wave waits for every lane's)
 enum : int { ZSTD_SEQ_STREAM = 4096, ZSTD_SEQ_PAD = 32, ZSTD_SEQ_LANE_BYTES = ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD + ZSTD_SEQ_STREAM };   // (PAD zero bytes in front of the stream: its window may begin below bit 0)
-CIMG_HD int zstd_seq_lds_bytes(int lanes) { return lanes * ZSTD_SEQ_LANE_BYTES + 64; }
+// (behind the lanes' areas: what the length codes mean, base | extra bits << 24 -- 36 literal length codes, 53 match length codes)
+enum : int { ZSTD_SEQ_CODES_BYTES = 4 * (36 + 53 + 7) };
+CIMG_HD int zstd_seq_lds_bytes(int lanes) { return lanes * ZSTD_SEQ_LANE_BYTES + ZSTD_SEQ_CODES_BYTES + 64; }
 
 // bits [p, p + 64) of a stream of bl bytes, p a multiple of 8 and any value; bits outside the stream read as zero
 CIMG_DEV uint64_t zstd_window64(const uint8_t* bs, int bl, int p)
@@ -37,6 +39,12 @@ struct ZstdSeqLanes {
     CIMG_DEV void run()
     {
         const int lanes = a.zlanes;
+        // the meaning of the length codes, once per workgroup: a lookup in the loop instead of a chain of comparisons per lane
+        uint32_t* const codes = reinterpret_cast<uint32_t*>(lds + lanes * ZSTD_SEQ_LANE_BYTES);
+        FOR_LANES_W(l) {
+            if (l < 36) codes[l] = (uint32_t)zstd_ll_base(l) | ((uint32_t)zstd_ll_bits(l) << 24);
+            if (l < 53) codes[36 + l] = (uint32_t)zstd_ml_base(l) | ((uint32_t)zstd_ml_bits(l) << 24);
+        }
         LV<uint8_t*> slot;                 // the lane's plan
         LV<int> njobs, job_i, rem, err;
         FOR_LANES(l) {
@@ -150,10 +158,11 @@ struct ZstdSeqLanes {
                             // (most sequences of an image have a literal length below 16 and a match length below 35: coded directly)
                             int llen = ls, mlen = ms + 3;
                             if (ls >= 16 || ms >= 32) {
-                                const int xb = zstd_ml_bits(ms), xc = zstd_ll_bits(ls);
-                                const uint32_t xm = take(c0[l], c1[l], lo[l], off[l], xb);
-                                const uint32_t xl = take(c0[l], c1[l], lo[l], off[l], xc);
-                                llen = zstd_ll_base(ls) + (int)xl; mlen = zstd_ml_base(ms) + (int)xm;
+                                cimg_lds_cu32p const C = CIMG_AS_LDS_CU32(lds + lanes * ZSTD_SEQ_LANE_BYTES);
+                                const uint32_t lc = C[ls], mc = C[36 + ms];
+                                const uint32_t xm = take(c0[l], c1[l], lo[l], off[l], (int)(mc >> 24));
+                                const uint32_t xl = take(c0[l], c1[l], lo[l], off[l], (int)(lc >> 24));
+                                llen = (int)(lc & 0xFFFFFF) + (int)xl; mlen = (int)(mc & 0xFFFFFF) + (int)xm;
                             }
                             const uint32_t ov = (1u << os) + xo;
                             if (rem[l] > 1) {

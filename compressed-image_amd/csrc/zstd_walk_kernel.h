@@ -15,9 +15,11 @@
 
 namespace cimg {
 
-enum : int { ZSTD_PLAN_OPS = 62, ZSTD_PLAN_JOBS_AT = 2048, ZSTD_PLAN_JOBS = 32, ZSTD_PLAN_HEAD = 3072, ZSTD_PLAN_TABLES = 4, ZSTD_PLAN_TABLE_BYTES = ZSTD_PLAN_TABLES * ZSTD_JOB_TABLE_BYTES };
+enum : int { ZSTD_PLAN_OPS = 62, ZSTD_PLAN_NLIT_AT = 2000, ZSTD_PLAN_JOBS_AT = 2048, ZSTD_PLAN_JOBS = 32, ZSTD_PLAN_LITJOBS_AT = 3072, ZSTD_PLAN_LITJOBS = 16, ZSTD_PLAN_HEAD = 4096,
+             ZSTD_PLAN_TABLES = 4, ZSTD_PLAN_TABLE_BYTES = ZSTD_PLAN_TABLES * (ZSTD_JOB_TABLE_BYTES + ZSTD_HUF_TABLE_BYTES) };   // (tables of four compressed blocks: FSE and Huffman)
 enum : int { ZPLAN_NOT_OURS = 0, ZPLAN_READY = 1, ZPLAN_FALLBACK = 2 };          // a plan's first word; negative: the block's error code
-static_assert(16 + ZSTD_PLAN_OPS * sizeof(ZstdOp) <= ZSTD_PLAN_JOBS_AT && ZSTD_PLAN_JOBS_AT + ZSTD_PLAN_JOBS * sizeof(ZstdSeqJob) <= ZSTD_PLAN_HEAD, "status, counts, ops and jobs in the head of a slot");
+static_assert(16 + ZSTD_PLAN_OPS * sizeof(ZstdOp) <= ZSTD_PLAN_NLIT_AT && ZSTD_PLAN_JOBS_AT + ZSTD_PLAN_JOBS * sizeof(ZstdSeqJob) <= ZSTD_PLAN_LITJOBS_AT &&
+              ZSTD_PLAN_LITJOBS_AT + ZSTD_PLAN_LITJOBS * sizeof(ZstdLitJob) <= ZSTD_PLAN_HEAD, "status, counts, ops and jobs in the head of a slot");
 // a slot: head (status, ops, records, jobs | the ops | the jobs), `cap` bytes of records, `cap` bytes of literals, and -- jobs for the
 // lane decoder -- room for the tables of ZSTD_PLAN_TABLES compressed blocks
 CIMG_HD int64_t zstd_plan_stride(int cap, bool jobs) { return ZSTD_PLAN_HEAD + 2 * (int64_t)((cap + 15) & ~15) + (jobs ? ZSTD_PLAN_TABLE_BYTES : 0); }
@@ -30,9 +32,9 @@ struct ZstdWalkBlock {
     int b;
     CIMG_DEV ZstdWalkBlock(const DecodeArgs& a_, uint8_t* lds_, int b_) : a(a_), lds(lds_), b(b_) {}
 
-    CIMG_DEV void say(int32_t* head, int status, int nops, int nrecs, int njobs = 0)
+    CIMG_DEV void say(int32_t* head, int status, int nops, int nrecs, int njobs = 0, int nlit = 0)
     {
-        FOR_LANES_W(l) { if (l == 0) { head[1] = nops; head[2] = nrecs; head[3] = njobs; head[0] = status; } }
+        FOR_LANES_W(l) { if (l == 0) { head[1] = nops; head[2] = nrecs; head[3] = njobs; head[ZSTD_PLAN_NLIT_AT / 4] = nlit; head[0] = status; } }
     }
     CIMG_DEV void run()
     {
@@ -55,6 +57,7 @@ struct ZstdWalkBlock {
             w->stream = 0;
             w->defer = a.zlanes > 0 ? 1 : 0;
             w->jobs = reinterpret_cast<ZstdSeqJob*>(slot + ZSTD_PLAN_JOBS_AT); w->job_cap = ZSTD_PLAN_JOBS; w->job_n = 0;
+            w->litjobs = reinterpret_cast<ZstdLitJob*>(slot + ZSTD_PLAN_LITJOBS_AT); w->litjob_cap = ZSTD_PLAN_LITJOBS; w->litjob_n = 0; w->huf_tab = 0;
             w->tabs = slot + ZSTD_PLAN_HEAD + 2 * (int64_t)cap; w->tab_cap = a.zlanes > 0 ? ZSTD_PLAN_TABLE_BYTES : 0; w->tab_n = 0; w->frame_jobs = 0;
         }
         int pos = g.bstart;
@@ -76,7 +79,7 @@ struct ZstdWalkBlock {
             } else if (cs > g.neblock) { say(head, ERR_DATA, 0, 0); return; }
             pos += payload;                                      // (run tokens and stored streams: the replay reads them in the chunk)
         }
-        say(head, ZPLAN_READY, zstd_field(&w->op_n), zstd_field(&w->rec_n), zstd_field(&w->job_n));
+        say(head, ZPLAN_READY, zstd_field(&w->op_n), zstd_field(&w->rec_n), zstd_field(&w->job_n), zstd_field(&w->litjob_n));
     }
 };
 

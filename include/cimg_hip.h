@@ -192,7 +192,7 @@ void  cimg_host_free(void* p);
 /* ---- kernel timing (HIP events on the engine's stream) ------------------------------------------- */
 enum { CIMG_K_ENCODE = 0, CIMG_K_LAYOUT = 1, CIMG_K_EMIT = 2, CIMG_K_DECODE = 3, CIMG_K_DEINTERLEAVE = 4, CIMG_K_DECODE_ZSTD = 5, CIMG_K_ENCODE_ZSTD = 6,
        /* CIMG_K_DECODE_ZSTD is the whole zstd read path of a batch; its launches are also timed one by one: */
-       CIMG_K_ZSTD_WALK = 7, CIMG_K_ZSTD_REPLAY = 8, CIMG_K_ZSTD_FUSED = 9, CIMG_K_ZSTD_SEQ = 10, CIMG_K_COUNT = 11 };
+       CIMG_K_ZSTD_WALK = 7, CIMG_K_ZSTD_REPLAY = 8, CIMG_K_ZSTD_FUSED = 9, CIMG_K_ZSTD_SEQ = 10, CIMG_K_ZSTD_LIT = 11, CIMG_K_COUNT = 12 };
 /* on = 0: off; on = n > 0: the kernels of every n-th batch call are bracketed by events (1 = every call).  Each
  * event record costs about 5 us of stream time, so a throughput run samples (bench.py: every 4th batch). */
 void cimg_engine_enable_timing(cimg_engine* e, int on);

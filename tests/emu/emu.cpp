@@ -7,6 +7,7 @@
 #include "zstd_kernel.h"
 #include "zstd_walk_kernel.h"
 #include "zstd_seq_kernel.h"
+#include "zstd_lit_kernel.h"
 #include "deinterleave_kernel.h"
 #include "assemble_kernel.h"
 #include "blosclz_kernel.h"
@@ -208,6 +209,16 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         if (lanes > 0) {
             DecodeArgs sa = zb;
             sa.lds_bytes = zstd_seq_lds_bytes(lanes);
+            {
+                DecodeArgs la = sa;
+                la.lds_bytes = zstd_lit_lds_bytes();
+                std::vector<uint8_t> ll((size_t)la.lds_bytes);
+                for (int g = 0; g * ZSTD_LIT_BLOCKS < plan.total_blocks; g++) {
+                    memset(ll.data(), 0xCD, ll.size());
+                    ZstdLitLanes w(la, ll.data(), g);
+                    w.run();
+                }
+            }
             std::vector<uint8_t> sl((size_t)sa.lds_bytes);
             for (int g = 0; g * lanes < plan.total_blocks; g++) {
                 memset(sl.data(), 0xCD, sl.size());

@@ -37,7 +37,7 @@ for fam in fams:
     ms, k = eng.kernel_time(hip.K_DECODE_ZSTD)
     eng.enable_timing(False)
     parts = []
-    for kid in (hip.K_ZSTD_WALK, hip.K_ZSTD_SEQ, hip.K_ZSTD_REPLAY, hip.K_ZSTD_FUSED):
+    for kid in (hip.K_ZSTD_WALK, hip.K_ZSTD_LIT, hip.K_ZSTD_SEQ, hip.K_ZSTD_REPLAY, hip.K_ZSTD_FUSED):
         pm, pk = eng.kernel_time(kid)
         if pk: parts.append("%s %.2f ms" % (hip.KERNELS[kid], pm / pk))
     print("   " + ", ".join(parts))
