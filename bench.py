@@ -556,6 +556,17 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
         total_c = float(cs.item())
     ems, en = eng.kernel_time(hip.K_ENCODE_ZSTD)
     zms, zn = eng.kernel_time(hip.K_DECODE_ZSTD)
+
+    def read_path_launches():
+        """The launches behind the cimg_decode_zstd timing id (the zstd read path of a batch: walk, the two lane decoders, replay;
+        cimg_decode_zstd itself only for blocks whose plan did not fit), each with its own event pair."""
+        parts = {}
+        for kid in (hip.K_ZSTD_WALK, hip.K_ZSTD_LIT, hip.K_ZSTD_SEQ, hip.K_ZSTD_REPLAY, hip.K_ZSTD_FUSED):
+            pm, pk = eng.kernel_time(kid)
+            if pk:
+                parts[hip.KERNELS[kid]] = {"launches": pk, "avg_us": round(pm / pk * 1e3, 1)}
+        return parts
+    own_parts = read_path_launches()
     eng.enable_timing(False)
     if not torch.equal(d_out, d_raw):
         print("bench.py --config 5: pixels differ after the timed region", file=sys.stderr)
@@ -582,7 +593,8 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
                          "frac": round((Cb + N) / (e_avg_s if dom_is_enc else z_avg_s) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": int(Cb + N), "avg_launch_us": round((e_avg_s if dom_is_enc else z_avg_s) * 1e6, 1)},
             "kernels": {"cimg_encode_streams_zstd": {"launches": en, "avg_us": round(e_avg_s * 1e6, 1)},
-                        "cimg_decode_zstd": {"launches": zn, "avg_us": round(z_avg_s * 1e6, 1)}},
+                        "cimg_decode_zstd": {"launches": zn, "avg_us": round(z_avg_s * 1e6, 1),
+                                             "what": "the zstd read path of a batch, first launch to last (one event pair around them)", "launches_of_the_path": own_parts}},
         }
     # ---- chunks as the reference writes them: libzstd on the host (outside the timed region), decoded by the same kernel -----------
     if rank == 0 and world == 1 and have_libzstd and not args.no_cpu_baseline:
@@ -611,6 +623,7 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
         for _ in range(3):
             eng.decompress_device(d_ref.data_ptr(), roff, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=cb)
         rms, rn = eng.kernel_time(hip.K_DECODE_ZSTD)
+        ref_parts = read_path_launches()
         eng.enable_timing(False)
         thr = min(visible_cores(), 16)
         outb = np.zeros(N, np.uint8)
@@ -624,6 +637,7 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
         out["reference_chunks"] = {
             "what": f"chunks as c-blosc2 would write them: libzstd {O.zstd_version()} at clevel {clevel} (zstd level {L.orc_zstd_level_of_clevel(clevel)}) under the checker's chunk layer",
             "compression_ratio": round(N / float(cb.sum()), 4), "decoded_bit_exact_by_cimg_decode_zstd": bool(ok),
+            "gpu_decode_launches": ref_parts,
             "gpu_decode_avg_us": round(rms / max(rn, 1) * 1e3, 1), "gpu_decode_GBps": round(N / (rms / max(rn, 1) * 1e-3) / 1e9, 3) if rn else None,
             "host_libzstd_compress_GBps": round(N / t_make / 1e9, 4), "host_compress_threads": cores,
             "host_libzstd_decompress_GBps": round(reps * N / td / 1e9, 3), "host_decompress_threads": thr}

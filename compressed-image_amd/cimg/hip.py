@@ -34,7 +34,7 @@ EXPORTS = (
     "cimg_compress_batch_device_begin", "cimg_compress_batch_device_fetch", "cimg_decompress_batch_device_begin", "cimg_decompress_batch_device_fetch",
     "cimg_decompress_batch_device_sized", "cimg_decompress_batch_device_begin_sized",
     "cimg_device_malloc", "cimg_device_free", "cimg_memcpy_h2d", "cimg_memcpy_d2h", "cimg_host_malloc", "cimg_host_free",
-    "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_engine_kernel_samples", "cimg_engine_decode_stats", "cimg_kernel_name",
+    "cimg_engine_enable_timing", "cimg_engine_reset_timing", "cimg_engine_kernel_time", "cimg_engine_kernel_samples", "cimg_engine_decode_stats", "cimg_engine_zstd_stats", "cimg_kernel_name",
     "cimg_engine_debug_stamps", "cimg_engine_read_stamps", "cimg_shared_engine", "cimg_context_cparams",
     # include/blosc2.h
     "blosc2_create_cctx", "blosc2_create_dctx", "blosc2_free_ctx", "blosc2_compress_ctx",
@@ -118,6 +118,8 @@ def load():
     L.cimg_engine_kernel_samples.argtypes = [vp, C.c_int, vp, C.c_int]
     L.cimg_engine_decode_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.cimg_engine_decode_stats.restype = None
+    L.cimg_engine_zstd_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.cimg_engine_zstd_stats.restype = None
     L.cimg_kernel_name.argtypes = [C.c_int]
     L.cimg_kernel_name.restype = C.c_char_p
     L.cimg_engine_debug_stamps.argtypes = [vp, C.c_int]
@@ -398,6 +400,11 @@ class Engine:
         a, b, c, d = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         load().cimg_engine_decode_stats(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
         return {"lean_batches": a.value, "blocks_left_to_general": b.value, "blocks_total": c.value, "zstd_batches": d.value}
+
+    def zstd_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        load().cimg_engine_zstd_stats(self.handle, C.byref(a), C.byref(b))
+        return {"zstd_batches": a.value, "blocks_refused": b.value}
 
 
 def cbuffer_sizes(chunk):

@@ -616,6 +616,12 @@ void cimg_engine_decode_stats(cimg_engine* e, int64_t* lean_batches, int64_t* bl
     if (zstd_batches) *zstd_batches = e->zstd_batches;
 }
 
+void cimg_engine_zstd_stats(cimg_engine* e, int64_t* zstd_batches, int64_t* blocks_refused)
+{
+    if (zstd_batches) *zstd_batches = e->zstd_batches;
+    if (blocks_refused) *blocks_refused = e->zstd_blocks_refused;
+}
+
 // diagnostics: per-workgroup {shader clock, 100 MHz clock, HW_ID, XCC_ID} x {start, end} of the most recent
 // encode (which = 0) or decode (which = 1) launch; 16 uint64 per workgroup (four stamps).  Returns the workgroup count.
 void cimg_engine_debug_stamps(cimg_engine* e, int on) { e->stamps = on != 0; }

@@ -206,6 +206,9 @@ int  cimg_engine_kernel_samples(cimg_engine* e, int kernel, float* ms, int max_s
  * those batches it left to cimg_decode_blocks (leftover blocks included), their block total, and how many batches needed
  * cimg_decode_zstd.  Any pointer may be NULL. */
 void cimg_engine_decode_stats(cimg_engine* e, int64_t* lean_batches, int64_t* blocks_left_to_general, int64_t* blocks_total, int64_t* zstd_batches);
+/* the zstd read path since the engine was created: batches that needed it, and blocks whose plan did not fit its slot (the walk
+ * refused them and cimg_decode_zstd decoded them behind the other launches).  Any pointer may be NULL. */
+void cimg_engine_zstd_stats(cimg_engine* e, int64_t* zstd_batches, int64_t* blocks_refused);
 const char* cimg_kernel_name(int kernel);
 
 /* ---- diagnostics: per-workgroup clock stamps of the most recent encode (0) / decode (1) launch ------

@@ -807,6 +807,53 @@ def test_zstd_chunks_decode_on_the_gpu(eng, golden_dir):
     L.blosc2_free_ctx(dctx)
 
 
+@pytest.mark.parametrize("form", ["lanes_8", "lanes_3", "walkers_decode_sequences", "fused", "plans_overflow"])
+def test_every_form_of_the_zstd_read_path_on_the_gpu(form, golden_dir, monkeypatch):
+    """The read path of zstd chunks is several launches (engine.hip: decompress_finish -- cimg_zstd_walk, cimg_zstd_lit beside
+    cimg_zstd_seq, cimg_zstd_replay) with cimg_decode_zstd behind them for blocks whose plan does not fit its slot.  Every form the
+    environment can select -- lanes per wave of the sequence decoder, sequences decoded by the walkers themselves, the fused
+    kernels alone, plans of 256 bytes (most blocks refused) -- decodes the golden chunks and a batch of local ones bit-exactly,
+    fails a damaged chunk by itself, and says how many plans were refused."""
+    env = {"lanes_8": {}, "lanes_3": {"CIMG_ZSTD_LANES": "3"}, "walkers_decode_sequences": {"CIMG_ZSTD_LANES": "0"},
+           "fused": {"CIMG_ZSTD_FUSED": "1"}, "plans_overflow": {"CIMG_ZSTD_PLAN_CAP": "256"}}[form]
+    for k in ("CIMG_ZSTD_LANES", "CIMG_ZSTD_FUSED", "CIMG_ZSTD_PLAN_CAP"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = hip.Engine(0)
+    try:
+        kat = np.load(os.path.join(golden_dir, "zstd_kat.npz"))
+        names = [str(n) for n in kat["chunks"]]
+        chunks = [kat["chunk|" + n].tobytes() for n in names]
+        bad = bytearray(chunks[0])
+        at = chunks[0].find(b"\x28\xb5\x2f\xfd")
+        for k in range(at + 5, at + 40):
+            bad[k] ^= 0x5A
+        batch = chunks + [bytes(bad)] + chunks[::-1]
+        outs, status = e.decompress_host(batch, check=False)
+        want = names + [None] + names[::-1]
+        for i, n in enumerate(want):
+            if n is None:
+                assert status[i] < 0
+            else:
+                assert status[i] == 0 and outs[i].tobytes() == kat["cin|" + n].tobytes(), (form, i, n)
+        if O.zstd_available():
+            # 8 MiB of each family as libzstd writes it at the reference's default level (one frame per block) and at a split one
+            for fam, clevel in ((synth.tiled_channel, 9), (synth.natural_channel, 9), (synth.natural_channel, 5)):
+                a = fam(np.float32, 2048, 1024)
+                raw = np.ascontiguousarray(a).view(np.uint8).ravel()
+                p = O.cparams(4, clevel=clevel, blocksize=32768, compcode=O.ZSTD)
+                made = [O.compress(p, raw[o:o + (4 << 20)])[1] for o in range(0, raw.size, 4 << 20)]
+                outs, status = e.decompress_host(made)
+                assert not status.any()
+                assert b"".join(o.tobytes() for o in outs) == raw.tobytes(), (form, fam.__name__, clevel)
+        st = e.zstd_stats()
+        assert st["zstd_batches"] >= 1
+        assert (st["blocks_refused"] > 0) == (form == "plans_overflow"), (form, st)
+    finally:
+        e.close()
+
+
 def test_zstd_chunks_made_on_this_box(eng, golden_dir):
     """Beyond the committed vectors: chunks of every element size, split and unsplit, made here with the box's own libzstd
     (skipped where there is none) and framed as c-blosc2 frames them (tests/golden/make_zstd_golden.py) -- 1 MiB each, ragged
