@@ -171,14 +171,15 @@ struct ZstdSeqLanes {
                                 sm[l] = mbase + (int)((V >> onb) & ((1u << mnb) - 1));
                                 sl[l] = lbase + (int)(V >> (onb + mnb));
                             }
-                            int offset;
-                            if (ov > 3) { offset = (int)(ov - 3); r2[l] = r1[l]; r1[l] = r0[l]; r0[l] = offset; }
-                            else {
-                                const int idx = (int)ov + (llen == 0 ? 1 : 0);
-                                if (idx == 1) offset = r0[l];
-                                else if (idx == 2) { offset = r1[l]; r1[l] = r0[l]; r0[l] = offset; }
-                                else { offset = idx == 3 ? r2[l] : r0[l] - 1; r2[l] = r1[l]; r1[l] = r0[l]; r0[l] = offset; }
-                            }
+                            // the history of repeat offsets (RFC 8878 3.1.1.5) as selects: a new offset pushes the three down; a repeat
+                            // code picks one (one further when the sequence has no literals; the fourth choice is the first minus one)
+                            // and moves it to the front
+                            const bool rep = ov <= 3;
+                            const int idx = (int)ov + (llen == 0 ? 1 : 0);
+                            const int offset = !rep ? (int)(ov - 3) : idx == 1 ? r0[l] : idx == 2 ? r1[l] : idx == 3 ? r2[l] : r0[l] - 1;
+                            r2[l] = (!rep || idx >= 3) ? r1[l] : r2[l];
+                            r1[l] = (!rep || idx >= 2) ? r0[l] : r1[l];
+                            r0[l] = offset;
                             if (off[l] < 0 || offset <= 0 || offset >= (1 << 22) || llen >= (1 << 21) || mlen >= (1 << 21)) err[l] = ERR_DATA;
                             else {
                                 *rec[l] = zstd_record((uint32_t)llen, (uint32_t)mlen, (uint32_t)offset);
@@ -199,14 +200,18 @@ struct ZstdSeqLanes {
         }
     }
 
-    // n bits (n <= 32) below position `off` of the 128-bit window c1:c0 = bits [lo, lo + 128); off moves down
+    // n bits (n <= 32) below position `off` of the 128-bit window c1:c0 = bits [lo, lo + 128); off moves down.  No branches: a
+    // position outside the window (a damaged stream only: the loop's window rule keeps a sound one inside) is pulled into it and the
+    // lane reads rubbish -- its stream then ends below bit 0 or above it, which is what the caller checks.
     static CIMG_DEV uint32_t take(uint64_t c0, uint64_t c1, int lo, int& off, int n)
     {
         off -= n;
-        const int s = off - lo;                                // >= 0 while the window rule of the loop holds; a damaged stream may break it
-        if (n <= 0 || s < 0 || s >= 128) return 0;
-        const uint64_t v = s >= 64 ? (c1 >> (s - 64)) : (s ? (c0 >> s) | (c1 << (64 - s)) : c0);
-        return (uint32_t)v & (uint32_t)((1ull << n) - 1);
+        int s = off - lo;
+        s = s < 0 ? 0 : (s > 127 ? 127 : s);
+        const uint64_t a = s < 64 ? c0 : c1, b = s < 64 ? c1 : 0ull;
+        const int sh = s & 63;
+        const uint64_t v = (a >> sh) | ((b << 1) << (63 - sh));
+        return (uint32_t)v & (uint32_t)((1ull << (n < 0 ? 0 : (n > 32 ? 32 : n))) - 1);
     }
 };
 
