@@ -1,0 +1,25 @@
+set -x
+out=gpurun_out/prof/r04
+mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 300 python bench.py --config 1 > $out/bench_config1.json 2> $out/bench_config1.err
+timeout -k 10 300 python bench.py --config 3 > $out/bench_config3.json 2> $out/bench_config3.err
+timeout -k 10 500 python bench.py --config 5 > $out/bench_config5.json 2> $out/bench_config5.err
+echo "[extra] config benches done"
+timeout -k 10 200 python tools/diag_stamps_hw.py > $out/decode_slots.txt 2>&1
+echo "[extra] slots done"
+{ echo "## tools/diag_zstd_dev.py (default: walk + lit + seq + replay)"; timeout -k 10 200 python tools/diag_zstd_dev.py 2>&1 | tail -4;
+  echo "## --clevel 5 (split planes)"; timeout -k 10 200 python tools/diag_zstd_dev.py --clevel 5 2>&1 | tail -4;
+  echo "## CIMG_ZSTD_LANES=0 (the walkers decode sequences and literals themselves)"; CIMG_ZSTD_LANES=0 timeout -k 10 200 python tools/diag_zstd_dev.py 2>&1 | tail -4;
+  echo "## CIMG_ZSTD_FUSED=1 (cimg_decode_zstd alone)"; CIMG_ZSTD_FUSED=1 timeout -k 10 200 python tools/diag_zstd_dev.py 2>&1 | tail -4; } > $out/zstd_read_path.txt
+echo "[extra] zstd read path done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/zkt -- python3 tools/diag_zstd_dev.py > $out/zkt.log 2>&1
+f=$(ls $out/zkt/*/*_kernel_stats.csv 2>/dev/null | head -1); if [ -n "$f" ]; then cp "$f" $out/zstd_kernel_stats.csv; fi
+echo "[extra] zstd rocprof done"
+timeout -k 10 900 bash tools/numbers.sh > $out/numbers.txt 2>&1
+echo "[extra] numbers done"
+{ echo "## CIMG_HOST_REGISTER_MIB=0 tools/diag_hostpin.py"; CIMG_HOST_REGISTER_MIB=0 timeout -k 10 200 python tools/diag_hostpin.py 2>&1 | tail -6;
+  echo "## CIMG_HOST_REGISTER_MIB=32 tools/diag_hostpin.py"; CIMG_HOST_REGISTER_MIB=32 timeout -k 10 200 python tools/diag_hostpin.py 2>&1 | tail -6;
+  echo "## tools/diag_real_sizes.py"; timeout -k 10 300 python tools/diag_real_sizes.py 2>&1 | tail -12;
+  echo "## tools/diag_pymodule.py"; timeout -k 10 300 python tools/diag_pymodule.py 2>&1 | tail -12; } > $out/host_path.txt
+echo "[extra] host path done"
