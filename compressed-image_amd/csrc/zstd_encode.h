@@ -211,7 +211,11 @@ CIMG_DEV int zstd_finish_frame(uint8_t* lds, int tab_off, int n, cimg_global_u8p
     bw.init(out, stream_at, cap);
     // ---- FSE: the last sequence first ---------------------------------------------------------------------------------------
     uint32_t st_ll = 0, st_of = 0, st_ml = 0;
-    for (int base = ((nseq - 1) >> 6) << 6; base >= 0; base -= 64) {          // batches of 64 records, highest first
+#ifdef CIMG_ABL_ZSTD_NO_FSE      /* timing experiment only: the sequences are not coded */
+    for (int base = -1; base >= 0; base -= 64) {
+#else
+    for (int base = ((nseq - 1) >> 6) << 6; base >= 0; base -= 64) {
+#endif          // batches of 64 records, highest first
         // (rp: the record BEFORE each one -- a sequence whose offset repeats the previous sequence's, and that has literals, is
         // coded as the first repeat offset, Offset_Value 1: no extra bits.  The decoder's first repeat offset always IS the previous
         // sequence's offset here -- a real offset becomes it, a repeat leaves it -- and starts at 1 for the first sequence; the

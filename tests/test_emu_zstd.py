@@ -176,7 +176,9 @@ def test_chunks_made_with_the_local_libzstd(golden_dir):
     # other block sizes: 128 and 64 KiB (the kernel's LDS follows the batch's largest block; unsplit streams above 64 KiB), 4 KiB
     a = synth.natural_channel(np.uint16, 512, 300)
     src = np.ascontiguousarray(a).view(np.uint8).ravel()
-    for bs in (131072, 65536, 4096):
+    # (147456 = 144 KiB: a stream longer than zstd's largest block -- frames of two blocks, the second with treeless literals or
+    # repeated tables and the history of repeat offsets carried over; through the lane decoders that is two jobs per frame)
+    for bs in (147456, 131072, 65536, 4096):
         for clevel in (3, 9):
             chunk = G.frame(z, src, 2, bs, clevel)
             rc, status, out = E.decompress_batch([chunk], [src.size], [bs])

@@ -887,7 +887,9 @@ def test_zstd_chunks_made_on_this_box(eng, golden_dir):
     # other block sizes: 128 and 64 KiB (the kernel's LDS follows the batch's largest block; unsplit streams above 64 KiB), 4 KiB
     a = synth.natural_channel(np.uint16, 1024, 600)
     src = np.ascontiguousarray(a).view(np.uint8).ravel()
-    for bs in (131072, 65536, 4096):
+    # (144 KiB: longer than zstd's largest block -- frames of two blocks, i.e. two jobs per frame for the lane decoders, the second
+    # with repeated tables / treeless literals and the repeat offsets carried over)
+    for bs in (147456, 131072, 65536, 4096):
         chunks = [G.frame(z, src, 2, bs, clevel) for clevel in (3, 9)]
         outs, status = eng.decompress_host(chunks)
         assert not status.any(), bs
