@@ -11,7 +11,7 @@
 
 namespace cimg {
 
-enum : int { ZSTD_LIT_BLOCKS = 16 };
+enum : int { ZSTD_LIT_BLOCKS = 8 };
 CIMG_HD int zstd_lit_lds_bytes() { return ZSTD_LIT_BLOCKS * ZSTD_HUF_TABLE_BYTES + 64; }
 
 struct ZstdLitLanes {
@@ -27,7 +27,7 @@ struct ZstdLitLanes {
         LV<int> njobs, job_i, rem, err;                      // per lane; the four lanes of a block move through its jobs together
         FOR_LANES(l) {
             const int k = g * ZSTD_LIT_BLOCKS + (l >> 2);
-            const bool mine = k < a.zblocks;
+            const bool mine = (l >> 2) < ZSTD_LIT_BLOCKS && k < a.zblocks;
             slot[l] = a.zplan + (int64_t)(mine ? k : 0) * a.zplan_stride;
             const int32_t* const head = reinterpret_cast<const int32_t*>(slot[l]);
             njobs[l] = (mine && head[0] == ZPLAN_READY) ? *reinterpret_cast<const int32_t*>(slot[l] + ZSTD_PLAN_NLIT_AT) : 0;
@@ -104,26 +104,38 @@ struct ZstdLitLanes {
                 LV<bool> now_idle;
                 FOR_LANES(l) {
                     if (rem[l] > 0) {
-                        // the 64 bits that end with the byte the reader stands in: at least 57 of them below the reader
-                        const int B = ((top[l] + 7) >> 3) - 8;
-                        const int lo = 8 * B;
-                        uint64_t c;
-                        if (B >= 0) __builtin_memcpy(&c, bs[l] + B, 8);
-                        else c = zstd_window64(bs[l], size[l], lo);
+                        // The 128 bits that end with the byte the reader stands in, in ONE read -- ten symbols a step: five from the
+                        // upper 64 bits (at least 57 of them below the reader, a code has at most 11), then the 64 bits that end with
+                        // the byte the reader has reached by then (cut out of the same 128), five more.
+                        const int B = ((top[l] + 7) >> 3) - 16;
+                        uint64_t c0, c1;
+                        if (B >= 0) { __builtin_memcpy(&c0, bs[l] + B, 8); __builtin_memcpy(&c1, bs[l] + B + 8, 8); }
+                        else { c0 = zstd_window64(bs[l], size[l], 8 * B); c1 = zstd_window64(bs[l], size[l], 8 * B + 64); }
                         cimg_lds_cu16p const T = CIMG_AS_LDS_CU16(lds + (l >> 2) * ZSTD_HUF_TABLE_BYTES);
                         const int lg = log[l];
                         const uint32_t mask = (1u << lg) - 1;
                         int t = top[l], n = rem[l];
                         uint8_t* o = out[l];
+                        uint64_t c = c1;
+                        int lo = 8 * B + 64;
                         CIMG_UNROLL
-                        for (int k = 0; k < 5; k++) {
-                            if (n > 0) {
-                                const int s = t - lg - lo;                     // (>= 0: lo <= t - 57 at the top of the step, at most 44 bits taken since)
-                                const uint32_t idx = (s >= 0 ? (uint32_t)(c >> s) : (uint32_t)(c << -s)) & mask;
-                                const uint32_t e = T[idx];
-                                *o++ = (uint8_t)e;
-                                t -= (int)(e >> 8);
-                                n -= 1;
+                        for (int half = 0; half < 2; half++) {
+                            CIMG_UNROLL
+                            for (int k = 0; k < 5; k++) {
+                                if (n > 0) {
+                                    const int s = t - lg - lo;                 // (>= 0: lo <= t - 57 at the top of the half, at most 44 bits taken since)
+                                    const uint32_t idx = (s >= 0 ? (uint32_t)(c >> s) : (uint32_t)(c << -s)) & mask;
+                                    const uint32_t e = T[idx];
+                                    *o++ = (uint8_t)e;
+                                    t -= (int)(e >> 8);
+                                    n -= 1;
+                                }
+                            }
+                            if (half == 0) {
+                                int d = ((t + 7) >> 3) - 8 - B;                // bytes the second window lies above the start of the 128 bits: 1 .. 8
+                                d = d < 0 ? 0 : (d > 8 ? 8 : d);               // (a damaged stream only)
+                                c = d >= 8 ? c1 : (d <= 0 ? c0 : (c0 >> (8 * d)) | (c1 << (64 - 8 * d)));
+                                lo = 8 * (B + d);
                             }
                         }
                         top[l] = t; rem[l] = n; out[l] = o;
