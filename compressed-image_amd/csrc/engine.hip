@@ -259,6 +259,7 @@ struct cimg_engine {
     // environment knobs are read ONCE, when the engine is created (diagnostics only; none changes results)
     bool verbose = getenv("CIMG_VERBOSE") != nullptr;
     int enc_wgs_limit = getenv("CIMG_ENC_WGS_PER_CU") ? atoi(getenv("CIMG_ENC_WGS_PER_CU")) : 0;
+    int enc_whole_rounds = getenv("CIMG_ENC_WHOLE_ROUNDS") ? atoi(getenv("CIMG_ENC_WHOLE_ROUNDS")) : 1 << 20;   // diagnostic: of the full rounds of a small batch, how many go out as whole blocks
     int enc_block_items = getenv("CIMG_ENC_BLOCK_ITEMS") ? atoi(getenv("CIMG_ENC_BLOCK_ITEMS")) : -1;   // -1: by batch size
     int enc_hybrid = getenv("CIMG_ENC_HYBRID") ? atoi(getenv("CIMG_ENC_HYBRID")) : 1;                  // 0: a small batch goes plane by plane throughout
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
@@ -724,14 +725,17 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
             for (const ChunkDesc& d : plan.descs)
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items_ok = false; break; }
         // how many of the blocks go out whole: all of them on a large batch; on a small one the rounds every chain takes anyway,
-        // while the last, partial round (where a coarser item would cost a whole extra item on the slowest chain) stays plane
-        // by plane.  configs[1]: 4096 blocks on 1280 chains = 3.2 rounds -> 3840 whole blocks, 256 plane by plane.
+        // while the END of the launch stays plane by plane, most significant planes first (encode_item_place): a coarser item would
+        // cost a whole extra item on the slowest chain, and the light planes (noise: 12 us against 77 for a coded one) are what idle
+        // chains fill the tail with.  When the last round is short (3.2 rounds on configs[1]) the full round in front of it goes plane
+        // by plane too: 4096 blocks on 1280 chains -> 2560 whole blocks, 1536 plane by plane: 369 -> 360 us (3 / 2 / 1 / 0 whole
+        // rounds: 369 / 360 / 366 / 380 -- a plane item reads its whole block, and costs a pop).
         int whole_blocks = 0;
         if (block_items_ok) {
             const int chains = std::max(1, e->lds_per_cu / std::max(lds_bytes, 1)) * e->num_cus;
             const double rounds = (double)plan.total_blocks / chains;
             if (e->enc_block_items == 1 || (e->enc_block_items < 0 && rounds >= 8.0)) whole_blocks = plan.total_blocks;
-            else if (e->enc_block_items < 0 && e->enc_hybrid) whole_blocks = std::min(plan.total_blocks, (int)rounds * chains);   // the FULL rounds
+            else if (e->enc_block_items < 0 && e->enc_hybrid) whole_blocks = std::min(plan.total_blocks, std::min(std::max(0, (int)(rounds - 0.5)), e->enc_whole_rounds) * chains);   // the full rounds, less the one in front of a short last round (CIMG_ENC_WHOLE_ROUNDS: at most so many)
         }
         const int items = encode_items(plan.total_blocks, plan.cp.streams_per_block, split != 0, whole_blocks);
         uint64_t* dbg = nullptr;
