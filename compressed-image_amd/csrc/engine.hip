@@ -1128,15 +1128,19 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
                     }
                 }
                 DecodeArgs ra = zb;
+                const bool fused_fits = zstd_kernel_lds_bytes(f.max_blocksize, 1) <= e->lds_per_wg;
                 ra.blk_first = g0; ra.lds_bytes = replay_lds;
+                ra.tune = fused_fits ? 0 : 2;                  // 2: a block the walk refuses has nobody to go to -- the replay fails its chunk
                 if ((rc = e->launch(CIMG_K_ZSTD_REPLAY, cimg_zstd_replay, ra, nb, 64, ra.lds_bytes))) return rc;
                 launched = true;
                 if ((rc = cimg_engine_synchronize(e))) return rc;
                 if (*refused) {
                     e->zstd_blocks_refused += *refused;
                     if (e->verbose) fprintf(stderr, "[cimg] zstd: %u of %d plans did not fit their slots (cimg_decode_zstd reads those blocks)\n", (unsigned)*refused, nb);
-                    if ((rc = fused(zb, g0, nb))) return rc;
-                    if ((rc = cimg_engine_synchronize(e))) return rc;
+                    if (fused_fits) {
+                        if ((rc = fused(zb, g0, nb))) return rc;
+                        if ((rc = cimg_engine_synchronize(e))) return rc;
+                    }
                 }
             }
         }

@@ -95,7 +95,12 @@ struct ZstdReplayBlock {
         const uint8_t* const slot = a.zplan + (int64_t)(b - a.blk_first) * a.zplan_stride;
         const int32_t* const head = reinterpret_cast<const int32_t*>(slot);
         const int status = (int)uni((uint32_t)head[0]), nops = (int)uni((uint32_t)head[1]), nrecs = (int)uni((uint32_t)head[2]);
-        if (status == ZPLAN_NOT_OURS || status == ZPLAN_FALLBACK) return;
+        if (status == ZPLAN_NOT_OURS) return;
+        if (status == ZPLAN_FALLBACK) {
+            // (a.tune & 2: blocks so large that cimg_decode_zstd cannot take over -- its LDS holds output AND tables: the chunk says so)
+            if (a.tune & 2) fail(find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks), ERR_CODEC_SUPPORT);
+            return;
+        }
         if (status != ZPLAN_READY) { fail(find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks), status < 0 ? status : ERR_FAILURE); return; }
         const int area = (a.lds_bytes - 64) & ~63;
         ZstdBlockGeom g;

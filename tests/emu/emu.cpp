@@ -187,6 +187,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     // (emu_set_zstd_plan: cap 0 = fused only; a small cap makes plans overflow).
     std::vector<uint8_t> zplan;
     uint32_t refused = 0;
+    bool no_fused = false;
     DecodeArgs zb = da;
     zb.done = nullptr;
     const bool planned = (unread[0] || unread[1]) && g_emu_zstd_plan_cap != 0;
@@ -227,6 +228,9 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
             }
         }
         DecodeArgs ra = zb;
+        const bool fused_fits = zstd_kernel_lds_bytes(max_bs, 1) <= 163840;          // (engine.hip: blocks the fused kernel's LDS cannot hold)
+        ra.tune = fused_fits ? 0 : 2;
+        if (!fused_fits) no_fused = true;
         ra.lds_bytes = zstd_replay_lds_bytes(max_bs);
         std::vector<uint8_t> rl((size_t)ra.lds_bytes);            // (exactly: the replay's dword fetches stay inside the launch's LDS)
         for (int b = 0; b < plan.total_blocks; b++) {
@@ -236,7 +240,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         }
         g_emu_zstd_refused += refused;
     }
-    const bool run_fused = (unread[0] || unread[1]) && (!planned || refused > 0);
+    const bool run_fused = (unread[0] || unread[1]) && (!planned || (refused > 0 && !no_fused));
     if (!run_fused) { unread[0] = false; unread[1] = false; }
     const bool two_waves = unread[1] && zstd_kernel_lds_bytes(max_bs, 2) <= 163840;       // (engine.hip: decompress_finish)
     if (!two_waves) { unread[0] = unread[0] || unread[1]; unread[1] = false; }

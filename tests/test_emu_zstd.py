@@ -146,7 +146,7 @@ def test_a_damaged_zstd_chunk_reports_an_error_and_leaves_its_neighbours_alone(k
     assert out[0].tobytes() == src.tobytes() and out[2].tobytes() == src.tobytes()
 
 
-def test_chunks_made_with_the_local_libzstd(golden_dir):
+def test_chunks_made_with_the_local_libzstd(golden_dir, zstd_read_path):
     """Beyond the committed vectors: every element size, split and unsplit, ragged last block -- made here with the system
     libzstd (skipped where there is none), decoded by the emulated kernels."""
     import ctypes as C
@@ -182,6 +182,11 @@ def test_chunks_made_with_the_local_libzstd(golden_dir):
         for clevel in (3, 9):
             chunk = G.frame(z, src, 2, bs, clevel)
             rc, status, out = E.decompress_batch([chunk], [src.size], [bs])
+            if bs == 147456 and zstd_read_path == "plans_overflow":
+                # (blocks the walk refuses go to cimg_decode_zstd, whose LDS holds output AND tables: 144 KiB blocks do not fit there --
+                # the chunk, and only the chunk, says so)
+                assert rc == 0 and status == [-7], (bs, clevel, status)
+                continue
             assert rc == 0 and status == [0], (bs, clevel, status)
             assert out[0].tobytes() == src.tobytes(), (bs, clevel)
 
