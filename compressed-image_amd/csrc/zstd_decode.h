@@ -1143,12 +1143,16 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
         int lsz = comp;
         bool ls_in_lds = !w->tail;                         // (a frame staged whole)
         if (comp <= stage_cap) { zstd_stage(w->stage, ls, comp); ls = w->stage; ls_in_lds = true; }
+        // (a section that does not fit the stage: its HEAD does -- the tree description is at most 129 bytes, and read byte by byte
+        // from global memory it is a load latency per byte: 0.2 ms a block, which was most of what a walker did)
+        const bool head_only = comp > stage_cap && stage_cap >= 256;
+        if (head_only && ltype == 2) zstd_stage(w->stage, ls, stage_cap);
         if (ltype == 2) {
 #ifdef CIMG_ABL_ZSTD_NO_TREE     /* timing experiment only: the table is not built (one with the same header length would be) */
             const int t = lsz > 130 ? 64 : 1;
             w->huf_log = 11;
 #else
-            const int t = zstd_huf_read_tree(ls, lsz, w);
+            const int t = head_only ? zstd_huf_read_tree(w->stage, stage_cap, w) : zstd_huf_read_tree(ls, lsz, w);
 #endif
             if (t < 0) return t;
             ls += t; lsz -= t;
@@ -1214,16 +1218,25 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
     }
     // ---- sequences section
     if (pos >= size) return ERR_DATA;
-    int nseq = zstd_u8(src, pos++);
+    // (of a frame in global memory the head of the section -- sequence count, modes, up to three table descriptions: some 160 bytes
+    // at most -- is brought into the stage first: the descriptions are read bit by bit.  hsrc[p - hdel] is byte p of the block.)
+    const uint8_t* hsrc = src;
+    int hdel = 0, hend = size;
+    if (stage_cap >= 512 && size - pos > 0) {
+        const int hb = imin(size - pos, stage_cap);
+        zstd_stage(w->stage, src + pos, hb);
+        hsrc = w->stage; hdel = pos; hend = pos + hb;
+    }
+    int nseq = zstd_u8(hsrc, pos++ - hdel);
     if (nseq >= 128) {
-        if (nseq == 255) { if (pos + 2 > size) return ERR_DATA; nseq = zstd_u8(src, pos) + (zstd_u8(src, pos + 1) << 8) + 0x7F00; pos += 2; }
-        else { if (pos + 1 > size) return ERR_DATA; nseq = ((nseq - 128) << 8) + zstd_u8(src, pos++); }
+        if (nseq == 255) { if (pos + 2 > hend) return ERR_DATA; nseq = zstd_u8(hsrc, pos - hdel) + (zstd_u8(hsrc, pos + 1 - hdel) << 8) + 0x7F00; pos += 2; }
+        else { if (pos + 1 > hend) return ERR_DATA; nseq = ((nseq - 128) << 8) + zstd_u8(hsrc, pos++ - hdel); }
     }
     int lpos = 0;                                          // literals consumed
     int rec_first = 0;
     if (nseq > 0) {
-        if (pos >= size) return ERR_DATA;
-        const int modes = zstd_u8(src, pos++);
+        if (pos >= hend) return ERR_DATA;
+        const int modes = zstd_u8(hsrc, pos++ - hdel);
         if (modes & 3) return ERR_DATA;
         for (int k = 0; k < 3; k++) {
             const int mode = (modes >> (6 - 2 * k)) & 3;
@@ -1237,13 +1250,13 @@ CIMG_DEV int zstd_block(const uint8_t* src, int size, uint8_t* dst, int dpos, in
                 const int rc = zstd_fse_build(t, *lg, nsym, w);
                 if (rc < 0) return rc;
             } else if (mode == 1) {
-                if (pos >= size) return ERR_DATA;
-                if (zstd_u8(src, pos) > maxsym) return ERR_DATA;
-                zstd_fse_rle(t, zstd_u8(src, pos++));
+                if (pos >= hend) return ERR_DATA;
+                if (zstd_u8(hsrc, pos - hdel) > maxsym) return ERR_DATA;
+                zstd_fse_rle(t, zstd_u8(hsrc, pos++ - hdel));
                 *lg = 0;
             } else if (mode == 2) {
                 int nsym = 0;
-                const int h = zstd_fse_read_header(src + pos, size - pos, maxlog, maxsym, w, lg, &nsym);
+                const int h = zstd_fse_read_header(hsrc + (pos - hdel), hend - pos, maxlog, maxsym, w, lg, &nsym);
                 if (h < 0) return h;
                 const int rc = zstd_fse_build(t, *lg, nsym, w);
                 if (rc < 0) return rc;

@@ -56,7 +56,7 @@ struct ZstdLitLanes {
                 const uint32_t* const jq = reinterpret_cast<const uint32_t*>(sl_t + ZSTD_PLAN_LITJOBS_AT + 64 * ji);
                 const uint32_t tab = uni(jq[5]), jlog = uni(jq[6]);
                 const bool bad = tab > (uint32_t)(ZSTD_PLAN_TABLE_BYTES - ZSTD_HUF_TABLE_BYTES) || (tab & 15) || jlog < 1 || jlog > (uint32_t)ZSTD_HUF_LOG_MAX;
-                if (!bad) wave_copy_g2l(sl_t + ZSTD_PLAN_HEAD + 2 * (int64_t)cap + tab, lds, (t >> 2) * ZSTD_HUF_TABLE_BYTES, (2 << jlog) < 16 ? 16 : (2 << jlog));
+                if (!bad) wave_copy_g2l(sl_t + zstd_plan_tabs_at(cap) + tab, lds, (t >> 2) * ZSTD_HUF_TABLE_BYTES, (2 << jlog) < 16 ? 16 : (2 << jlog));
                 FOR_LANES(l) {
                     if ((l & ~3) == t) {
                         const ZstdLitJob* const job = reinterpret_cast<const ZstdLitJob*>(slot[l] + ZSTD_PLAN_LITJOBS_AT) + job_i[l];
@@ -69,7 +69,7 @@ struct ZstdLitLanes {
                         bs[l] = nullptr; size[l] = 0; rem[l] = 0;
                         if (bad || lsz < 1 || lsz > (1 << 24) || regen < 0 || jout < 0 || regen > cap - jout || (streams != 1 && streams != 4)) e = ERR_DATA;
                         else if (streams == 1) {
-                            if (j == 0) { bs[l] = p; size[l] = lsz; rem[l] = regen; out[l] = slot[l] + ZSTD_PLAN_HEAD + cap + jout; }
+                            if (j == 0) { bs[l] = p; size[l] = lsz; rem[l] = regen; out[l] = slot[l] + zstd_plan_lits_at(cap) + jout; }
                         } else if (lsz < 6) e = ERR_DATA;
                         else {
                             const int s1 = p[0] | (p[1] << 8), s2 = p[2] | (p[3] << 8), s3 = p[4] | (p[5] << 8);
@@ -80,7 +80,7 @@ struct ZstdLitLanes {
                                 bs[l] = p + 6 + (j > 0 ? s1 : 0) + (j > 1 ? s2 : 0) + (j > 2 ? s3 : 0);
                                 size[l] = j == 0 ? s1 : j == 1 ? s2 : j == 2 ? s3 : s4;
                                 rem[l] = j == 3 ? regen - 3 * per : per;
-                                out[l] = slot[l] + ZSTD_PLAN_HEAD + cap + jout + j * per;
+                                out[l] = slot[l] + zstd_plan_lits_at(cap) + jout + j * per;
                             }
                         }
                         if (e == 0 && rem[l] > 0) {

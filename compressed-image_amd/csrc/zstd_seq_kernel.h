@@ -13,9 +13,14 @@
 
 namespace cimg {
 
-// a lane's LDS: its job's tables, and ZSTD_SEQ_STREAM bytes for the job's bit stream -- brought over in one wide copy when it fits
-// (a stream read where it lies costs a trip to global memory per 64 bits, and the wave waits for every lane's)
-enum : int { ZSTD_SEQ_STREAM = 4096, ZSTD_SEQ_PAD = 32, ZSTD_SEQ_LANE_BYTES = ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD + ZSTD_SEQ_STREAM };   // (PAD zero bytes in front of the stream: its window may begin below bit 0)
+// a lane's LDS: its job's tables, and ZSTD_SEQ_STREAM bytes of the job's bit stream -- the END of it first (a stream is read from its
+// last byte down), brought over in one wide copy by the whole wave, and the ZSTD_SEQ_STREAM bytes below the reader again whenever it
+// gets to the bottom of what is there (a stream read where it lies costs a trip to global memory per step, and the wave waits for
+// every lane's)
+#ifndef CIMG_ZSTD_SEQ_STREAM
+#define CIMG_ZSTD_SEQ_STREAM 4096      /* (tests build the emulator once more with 256: every stream is refilled many times) */
+#endif
+enum : int { ZSTD_SEQ_STREAM = CIMG_ZSTD_SEQ_STREAM, ZSTD_SEQ_PAD = 32, ZSTD_SEQ_LANE_BYTES = ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD + ZSTD_SEQ_STREAM };   // (PAD zero bytes in front of the stream: its window may begin below bit 0)
 // (behind the lanes' areas: what the length codes mean, base | extra bits << 24 -- 36 literal length codes, 53 match length codes)
 enum : int { ZSTD_SEQ_CODES_BYTES = 4 * (36 + 53 + 7) };
 CIMG_HD int zstd_seq_lds_bytes(int lanes) { return lanes * ZSTD_SEQ_LANE_BYTES + ZSTD_SEQ_CODES_BYTES + 64; }
@@ -61,10 +66,19 @@ struct ZstdSeqLanes {
         LV<uint64_t*> rec;
         LV<int> bl, off, lo, sl, so, sm, r0, r1, r2, llm, ofm, mlm;
         LV<uint64_t> c0, c1;               // bits [lo, lo + 64), [lo + 64, lo + 128) of the stream: read anew for every sequence
-        LV<bool> inlds;                    // the stream lies in the lane's LDS (zero bytes in front of it)
+        LV<int> w0;                        // the lane's LDS holds bytes [w0, w0 + ZSTD_SEQ_STREAM) of its stream (zero bytes in front of byte 0)
         FOR_LANES(l) { bs[l] = nullptr; rec[l] = nullptr; bl[l] = 0; off[l] = 0; lo[l] = 0; sl[l] = so[l] = sm[l] = 0; r0[l] = 1; r1[l] = 4; r2[l] = 8;
-                       llm[l] = ofm[l] = mlm[l] = 0; c0[l] = c1[l] = 0; inlds[l] = false; }
+                       llm[l] = ofm[l] = mlm[l] = 0; c0[l] = c1[l] = 0; w0[l] = 0; }
         const int cap = (a.zcap + 15) & ~15;
+        // bytes [from, from + ZSTD_SEQ_STREAM) of lane t's stream (as many as it has) into the lane's LDS: 16-byte units wide, the last
+        // bytes one by one; the zero bytes in front (they are read as the bits below bit 0 when from == 0)
+        auto stage_stream = [&](int t, const uint8_t* jbs, int jbl, int from) {
+            const int at = t * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD;
+            const int n = imin((int)ZSTD_SEQ_STREAM, jbl - from);
+            FOR_LANES_W(l) { if (l < ZSTD_SEQ_PAD) lds[at - ZSTD_SEQ_PAD + l] = 0; }
+            wave_copy_g2l(jbs + from, lds, at, n & ~15);
+            FOR_LANES_W(l) { if (l < (n & 15)) lds[at + (n & ~15) + l] = jbs[from + (n & ~15) + l]; }
+        };
         for (int guard = 0; guard < (1 << 30); ++guard) {
             // ---- lanes between jobs: the next job's tables into the lane's LDS, its reader and states set up
             LV<bool> want;
@@ -79,27 +93,23 @@ struct ZstdSeqLanes {
                 const uint32_t tab = uni(jq[5]);
                 int bad = 0;
                 if (tab > (uint32_t)(ZSTD_PLAN_TABLE_BYTES - ZSTD_JOB_TABLE_BYTES) || (tab & 15)) bad = 1;
-                if (!bad) wave_copy_g2l(sl_t + ZSTD_PLAN_HEAD + 2 * (int64_t)cap + tab, lds, t * ZSTD_SEQ_LANE_BYTES, ZSTD_JOB_TABLE_BYTES);
+                if (!bad) wave_copy_g2l(sl_t + zstd_plan_tabs_at(cap) + tab, lds, t * ZSTD_SEQ_LANE_BYTES, ZSTD_JOB_TABLE_BYTES);
                 // the bit stream beside them when it fits: whole 16-byte units wide, the last bytes one by one
                 const uint32_t jbl = uni(jq[2]);
                 const uint8_t* const jbs = reinterpret_cast<const uint8_t*>((uintptr_t)((uint64_t)uni(jq[0]) | ((uint64_t)uni(jq[1]) << 32)));
-                const bool staged = !bad && jbl >= 1 && jbl <= (uint32_t)ZSTD_SEQ_STREAM;
-                if (staged) {
-                    const int at = t * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD;
-                    FOR_LANES_W(l) { if (l < ZSTD_SEQ_PAD) lds[at - ZSTD_SEQ_PAD + l] = 0; }
-                    wave_copy_g2l(jbs, lds, at, (int)(jbl & ~15u));
-                    FOR_LANES_W(l) { if (l < (int)(jbl & 15u)) lds[at + (jbl & ~15u) + l] = jbs[(jbl & ~15u) + l]; }
-                }
+                const bool sane = !bad && jbl >= 1 && jbl <= (1u << 24);
+                const int from0 = sane ? imax(0, (int)jbl - (int)ZSTD_SEQ_STREAM) : 0;
+                if (sane) stage_stream(t, jbs, (int)jbl, from0);
                 FOR_LANES(l) {
                     if (l == t) {
                         const ZstdSeqJob* const job = reinterpret_cast<const ZstdSeqJob*>(slot[l] + ZSTD_PLAN_JOBS_AT) + job_i[l];
                         const ZstdSeqJob j = *job;
                         job_i[l] += 1;
-                        const int nrecs = cap >> 3;
+                        const int nrecs = zstd_plan_records(cap);
                         if (bad || j.bl < 1 || j.bl > (1u << 24) || j.nseq < 1 || j.nseq > (uint32_t)nrecs || j.rec > (uint32_t)nrecs - j.nseq || j.ll_log > 9 || j.of_log > 8 || j.ml_log > 9) err[l] = ERR_DATA;
                         else {
-                            bs[l] = staged ? lds + l * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD : reinterpret_cast<const uint8_t*>((uintptr_t)j.bs);
-                            inlds[l] = staged;
+                            bs[l] = reinterpret_cast<const uint8_t*>((uintptr_t)j.bs);
+                            w0[l] = from0;
                             bl[l] = (int)j.bl;
                             rec[l] = reinterpret_cast<uint64_t*>(slot[l] + ZSTD_PLAN_HEAD) + j.rec;
                             rem[l] = (int)j.nseq;
@@ -126,6 +136,26 @@ struct ZstdSeqLanes {
             if (!ballot(act)) break;
             // ---- one sequence per lane and step, until a lane is through with its job
             for (;;) {
+                // a lane whose reader has got to the bottom of what its LDS holds of the stream: the ZSTD_SEQ_STREAM bytes that end where
+                // it stands, by the whole wave (where the stream lies is read from the lane's job again: nothing of it is kept in
+                // registers)
+                {
+                    LV<bool> low;
+                    FOR_LANES(l) { low[l] = rem[l] > 0 && err[l] == 0 && w0[l] > 0 && ((off[l] + 7) >> 3) - 16 < w0[l]; }
+                    uint64_t refill = ballot(low);
+                    while (refill) {
+                        const int t = ctz64(refill);
+                        refill &= refill - 1;
+                        const uint8_t* const sl_t = a.zplan + (int64_t)(g * lanes + t) * a.zplan_stride;
+                        const uint32_t* const jq = reinterpret_cast<const uint32_t*>(sl_t + ZSTD_PLAN_JOBS_AT + 32 * (uni(readlane(job_i, t)) - 1));
+                        const uint8_t* const jbs = reinterpret_cast<const uint8_t*>((uintptr_t)((uint64_t)uni(jq[0]) | ((uint64_t)uni(jq[1]) << 32)));
+                        const int jbl = (int)uni(jq[2]);
+                        const int top = (uni(readlane(off, t)) + 7) >> 3;                       // the byte the reader stands in (exclusive end)
+                        const int from = imax(0, imin(top, jbl) - (int)ZSTD_SEQ_STREAM);
+                        stage_stream(t, jbs, jbl, from);
+                        FOR_LANES(l) { if (l == t) w0[l] = from; }
+                    }
+                }
                 LV<bool> through;
                 FOR_LANES(l) {
                     through[l] = false;
@@ -136,16 +166,13 @@ struct ZstdSeqLanes {
                         {
                             const int B = ((off[l] + 7) >> 3) - 16;
                             lo[l] = 8 * B;
-                            if (inlds[l]) {
-                                cimg_lds_cu8p const q = CIMG_AS_LDS_CU8(lds + l * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD) + (B < -ZSTD_SEQ_PAD ? -ZSTD_SEQ_PAD : B);
-                                uint64_t lo64, hi64;
-                                __builtin_memcpy(&lo64, q, 8);
-                                __builtin_memcpy(&hi64, q + 8, 8);
-                                c0[l] = lo64; c1[l] = hi64;
-                            } else {
-                                c0[l] = zstd_window64(bs[l], bl[l], lo[l]);
-                                c1[l] = zstd_window64(bs[l], bl[l], lo[l] + 64);
-                            }
+                            int rel = B - w0[l];                               // (>= 0 after the refill step above, or w0 == 0: the zero bytes)
+                            rel = rel < -ZSTD_SEQ_PAD ? -ZSTD_SEQ_PAD : (rel > ZSTD_SEQ_STREAM - 16 ? ZSTD_SEQ_STREAM - 16 : rel);
+                            cimg_lds_cu8p const q = CIMG_AS_LDS_CU8(lds + l * ZSTD_SEQ_LANE_BYTES + ZSTD_JOB_TABLE_BYTES + ZSTD_SEQ_PAD) + rel;
+                            uint64_t lo64, hi64;
+                            __builtin_memcpy(&lo64, q, 8);
+                            __builtin_memcpy(&hi64, q + 8, 8);
+                            c0[l] = lo64; c1[l] = hi64;
                         }
                         cimg_lds_cu32p const T = CIMG_AS_LDS_CU32(lds + l * ZSTD_SEQ_LANE_BYTES);
                         const uint32_t pl = T[sl[l] & llm[l]], pm = T[512 + (sm[l] & mlm[l])], po = T[1024 + (so[l] & ofm[l])];

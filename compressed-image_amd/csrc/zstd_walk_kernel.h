@@ -20,9 +20,14 @@ enum : int { ZSTD_PLAN_OPS = 62, ZSTD_PLAN_NLIT_AT = 2000, ZSTD_PLAN_JOBS_AT = 2
 enum : int { ZPLAN_NOT_OURS = 0, ZPLAN_READY = 1, ZPLAN_FALLBACK = 2 };          // a plan's first word; negative: the block's error code
 static_assert(16 + ZSTD_PLAN_OPS * sizeof(ZstdOp) <= ZSTD_PLAN_NLIT_AT && ZSTD_PLAN_JOBS_AT + ZSTD_PLAN_JOBS * sizeof(ZstdSeqJob) <= ZSTD_PLAN_LITJOBS_AT &&
               ZSTD_PLAN_LITJOBS_AT + ZSTD_PLAN_LITJOBS * sizeof(ZstdLitJob) <= ZSTD_PLAN_HEAD, "status, counts, ops and jobs in the head of a slot");
-// a slot: head (status, ops, records, jobs | the ops | the jobs), `cap` bytes of records, `cap` bytes of literals, and -- jobs for the
-// lane decoder -- room for the tables of ZSTD_PLAN_TABLES compressed blocks
-CIMG_HD int64_t zstd_plan_stride(int cap, bool jobs) { return ZSTD_PLAN_HEAD + 2 * (int64_t)((cap + 15) & ~15) + (jobs ? ZSTD_PLAN_TABLE_BYTES : 0); }
+// a slot: head (status, ops, records, jobs | the ops | the jobs), 2 x `cap` bytes of records, `cap` bytes of literals, and -- jobs for the
+// lane decoders -- room for the tables of ZSTD_PLAN_TABLES compressed blocks
+// (cap = the 16-byte multiple above the block area.  Records: 2 x cap bytes = a sequence per four bytes of the block -- what byte-wide
+// photographs at level 22 come to; denser blocks are refused.  Literals: cap bytes.)
+CIMG_HD int zstd_plan_records(int cap) { return (2 * cap) >> 3; }
+CIMG_HD int64_t zstd_plan_lits_at(int cap) { return ZSTD_PLAN_HEAD + 2 * (int64_t)cap; }
+CIMG_HD int64_t zstd_plan_tabs_at(int cap) { return ZSTD_PLAN_HEAD + 3 * (int64_t)cap; }
+CIMG_HD int64_t zstd_plan_stride(int cap, bool jobs) { return zstd_plan_tabs_at((cap + 15) & ~15) + (jobs ? ZSTD_PLAN_TABLE_BYTES : 0); }
 CIMG_HD int zstd_walk_lds_bytes(int stage = ZSTD_KERNEL_STAGE) { return ((stage + 15) & ~15) + zstd_work_bytes() + 64; }
 CIMG_HD int zstd_replay_lds_bytes(int max_blocksize) { return zstd_kernel_area(max_blocksize) + 64; }
 
@@ -52,13 +57,13 @@ struct ZstdWalkBlock {
             w->stage = stage; w->stage_cap = stage_cap; w->tail = 1;
             w->mem_lo = lds; w->mem_hi = lds + (a.lds_bytes & ~3);                    // ("this is the kernel": tables and stage are LDS)
             w->ops = reinterpret_cast<ZstdOp*>(slot + 16); w->op_cap = ZSTD_PLAN_OPS; w->op_n = 0;
-            w->recs = reinterpret_cast<uint64_t*>(slot + ZSTD_PLAN_HEAD); w->rec_cap = cap >> 3; w->rec_n = 0;
-            w->lits = slot + ZSTD_PLAN_HEAD + cap; w->lit_cap = cap; w->lit_n = 0;
+            w->recs = reinterpret_cast<uint64_t*>(slot + ZSTD_PLAN_HEAD); w->rec_cap = zstd_plan_records(cap); w->rec_n = 0;
+            w->lits = slot + zstd_plan_lits_at(cap); w->lit_cap = cap; w->lit_n = 0;
             w->stream = 0;
             w->defer = a.zlanes > 0 ? 1 : 0;
             w->jobs = reinterpret_cast<ZstdSeqJob*>(slot + ZSTD_PLAN_JOBS_AT); w->job_cap = ZSTD_PLAN_JOBS; w->job_n = 0;
             w->litjobs = reinterpret_cast<ZstdLitJob*>(slot + ZSTD_PLAN_LITJOBS_AT); w->litjob_cap = ZSTD_PLAN_LITJOBS; w->litjob_n = 0; w->huf_tab = 0;
-            w->tabs = slot + ZSTD_PLAN_HEAD + 2 * (int64_t)cap; w->tab_cap = a.zlanes > 0 ? ZSTD_PLAN_TABLE_BYTES : 0; w->tab_n = 0; w->frame_jobs = 0;
+            w->tabs = slot + zstd_plan_tabs_at(cap); w->tab_cap = a.zlanes > 0 ? ZSTD_PLAN_TABLE_BYTES : 0; w->tab_n = 0; w->frame_jobs = 0;
         }
         int pos = g.bstart;
         for (int s = 0; s < g.ns; s++) {
@@ -107,7 +112,7 @@ struct ZstdReplayBlock {
         const int ours = g.parse(a, b, area, 0);
         if (ours <= 0) { if (ours < 0) fail(g.chunk, ours); return; }            // (the walker saw the same header)
         const int cap = (a.zcap + 15) & ~15;
-        if (nops < 0 || nops > ZSTD_PLAN_OPS || nrecs < 0 || nrecs > (cap >> 3)) { fail(g.chunk, ERR_FAILURE); return; }
+        if (nops < 0 || nops > ZSTD_PLAN_OPS || nrecs < 0 || nrecs > zstd_plan_records(cap)) { fail(g.chunk, ERR_FAILURE); return; }
         const ZstdOp* const ops = reinterpret_cast<const ZstdOp*>(slot + 16);
         const uint64_t* const recs = reinterpret_cast<const uint64_t*>(slot + ZSTD_PLAN_HEAD);
         int pos = g.bstart, opi = 0;

@@ -22,6 +22,8 @@ class CParams(C.Structure):
 
 
 def build():
+    if os.environ.get("CIMG_EMU_LIB"):                 # (a test that runs this module against a differently built emulator)
+        return os.environ["CIMG_EMU_LIB"]
     deps = [_SRC] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(d) > os.path.getmtime(_LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra",

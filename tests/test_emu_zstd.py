@@ -358,3 +358,23 @@ def test_randomized_geometries_zstd_and_lz4hc_on_the_emulated_kernels():
             assert rc == 0 and not any(status), (what, status)
             for o, (_, n, at) in zip(outs, live):
                 assert o.tobytes() == raw[at:at + n].tobytes(), what
+
+
+def test_sequence_bit_streams_longer_than_a_lanes_lds(golden_dir, zstd_read_path):
+    """cimg_zstd_seq keeps 4 KiB of a job's bit stream in the lane's LDS and brings the next 4 KiB over when the reader reaches the
+    bottom (zstd_seq_kernel.h: the refill step).  The emulator built once more with 256 bytes instead -- every stream of the chunk
+    tests is refilled many times -- runs the chunk tests of this file again."""
+    import subprocess
+    import sys
+    if zstd_read_path != "planned":
+        pytest.skip("once is enough: the child runs the forms with lanes itself")
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(os.path.dirname(here), "compressed-image_amd", "csrc")
+    lib = os.path.join(here, "emu", "libcimg_emu_stream256.so")
+    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-w", "-fno-strict-aliasing", "-DCIMG_ZSTD_SEQ_STREAM=256",
+                           "-I", csrc, os.path.join(here, "emu", "emu.cpp"), "-o", lib])
+    env = dict(os.environ, CIMG_EMU_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "(blosc2_zstd_chunks_decode or local_libzstd or split_and_unsplit or damaged) and (planned or lanes)"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
