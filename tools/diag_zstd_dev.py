@@ -37,6 +37,10 @@ for fam in fams:
     for _ in range(3): eng.decompress_device(d_comp.ptr, coff, [CHUNK] * nch, [32768] * nch, d_out.ptr, roff, comp_size=cb)
     ms, k = eng.kernel_time(hip.K_DECODE_ZSTD)
     eng.enable_timing(False)
+    if not k:
+        print("%s %s clevel %d: no chunk went through the zstd read path (stored chunks: ratio %.2f)" % (fam, dtype.name, clevel, n / float(cb.sum())))
+        d_comp.free(); d_out.free()
+        continue
     parts = []
     for kid in (hip.K_ZSTD_WALK, hip.K_ZSTD_LIT, hip.K_ZSTD_SEQ, hip.K_ZSTD_REPLAY, hip.K_ZSTD_FUSED):
         pm, pk = eng.kernel_time(kid)
