@@ -876,6 +876,14 @@ CIMG_DEV_NOINLINE int lz4_encode_wave(uint8_t* lds_passed, int in_off, int tab_o
     return result;
 }
 
+}  // namespace cimg
+#include "encode_rt_kernel.h"   // the same encoder with its hash table in registers (round 5): EncodeStream<CODEC_LZ4_RT>
+namespace cimg {
+
+// EncodeStream's template argument for the register-table form of the LZ4 encoder (not a blosc2 codec id: the chunks are LZ4 / LZ4HC
+// chunks, byte for byte those of EncodeStream<CODEC_LZ4>)
+enum : int { CODEC_LZ4_RT = 101 };
+
 // true if all n bytes of the LDS plane equal its first byte
 CIMG_DEV bool plane_is_run(const uint8_t* in, int n, uint32_t& value)
 {
@@ -1367,6 +1375,7 @@ struct EncodeStream {
                 }
                 need = cb;                                    // a frame fits a budget iff the budget holds its bytes
             }
+            else if constexpr (CODEC == CODEC_LZ4_RT) cb = lz4_encode_rt_body(lds, neblock, out, neblock, accel_or_level, need);
             else cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, accel_or_level, &need, dbg, item);
             if (cb > 0 && cb < neblock) {
                 r.kind = REC_LZ4; r.csize = cb; r.need = need;
@@ -1394,7 +1403,10 @@ struct EncodeStream {
         int neblock, accel_or_level, rec_index, planes = 1, ts = 1;
         uint8_t* out;
         uint64_t* dbg;
-        LV<uint32_t> keep[96];                 // block items: the byte planes that wait for their turn (dead otherwise)
+        // block items: the byte planes that wait for their turn (dead otherwise).  The register-table encoder keeps its table where
+        // these would live: its launches hand out planes only (engine.hip sets block_items = 0)
+        constexpr bool BLOCK_ITEMS = CODEC != CODEC_LZ4_RT;
+        LV<uint32_t> keep[BLOCK_ITEMS ? 96 : 1];
         {
             const auto a = fresh(ap);
             int b, s;
@@ -1414,7 +1426,7 @@ struct EncodeStream {
             const uint8_t* src = a->raw + d.raw_off + (int64_t)j * d.blocksize;
             const int filter = a->p.filter;
             const bool shuf = filter == FILTER_SHUFFLE && ts > 1;
-            const bool whole = ns > 1 && item < a->block_items;          // host guarantees: typesize 2 or 4, 32 KiB, byte shuffle
+            const bool whole = BLOCK_ITEMS && ns > 1 && item < a->block_items;          // host guarantees: typesize 2 or 4, 32 KiB, byte shuffle
             if (whole) { planes = ns; s = ns - 1; }
             out = a->scratch + (int64_t)b * a->p.slot_bytes + (int64_t)s * neblock;
             rec_index = b * a->p.streams_per_block + s;
@@ -1426,7 +1438,8 @@ struct EncodeStream {
             debug_stamp(dbg, item, 0);                                   // diagnostics (tools/diag_enctimeline.py): item taken
             if (dbg && __lane_id() == 0) dbg[16 * (size_t)item + 4] = (uint64_t)w;
 #endif
-            if (whole) { if (ts == 2) load_block_ts2(src, keep); else load_block_ts4(src, keep); }
+            if constexpr (BLOCK_ITEMS) { if (whole) { if (ts == 2) load_block_ts2(src, keep); else load_block_ts4(src, keep); } }
+            if (whole) {}
             else if (ns > 1) load_plane(src, bsize, ts, s, neblock, shuf);
             else if (filter == FILTER_BITSHUFFLE) load_block_bitshuffle(src, bsize, ts);
             else load_block(src, bsize, ts, shuf);
@@ -1438,7 +1451,7 @@ struct EncodeStream {
         // LDS (ONE call site: the codec body is large and must exist once in the kernel)
         for (int s = planes - 1; s >= 0; --s) {
             if (s != planes - 1) {
-                restore_plane(keep, ts, s);
+                if constexpr (BLOCK_ITEMS) restore_plane(keep, ts, s);
                 out -= neblock;
                 rec_index -= 1;
             }

@@ -51,6 +51,14 @@ extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode
     encode_gang<CODEC_LZ4>(lds);
 }
 
+// LZ4 / LZ4HC streams with the hash table in registers (encode_rt_kernel.h): LDS is the plane alone, eight chains a CU
+extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode_streams_rt(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    (void)a;
+    encode_gang<CODEC_LZ4_RT>(lds);
+}
+
 extern "C" __global__ __launch_bounds__(CIMG_ENC_GANG_MAX * 64) void cimg_encode_streams_blosclz(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -251,6 +259,7 @@ struct cimg_engine {
     int enc_waves_cu = 1;               // encode waves per CU the registers allow (occupancy query, cached with enc_wgs_lds)
     int lds_per_cu = 163840, lds_per_wg = 65536;      // device properties
     int enc_gang = getenv("CIMG_ENC_GANG") ? atoi(getenv("CIMG_ENC_GANG")) : 0;
+    int enc_rt = getenv("CIMG_ENC_RT") ? atoi(getenv("CIMG_ENC_RT")) : 1;   // LZ4 / LZ4HC: the encoder with its hash table in registers (encode_rt_kernel.h); 0: the LDS-table form
     int enc_said_lds = -1, enc_said_gang = -1;
     int enc_wgs_lds[2] = {-1, -1};
     int enc_wgs_codec = -1;
@@ -265,7 +274,7 @@ struct cimg_engine {
     int lean_lds_pad = getenv("CIMG_LEAN_LDS_PAD") ? atoi(getenv("CIMG_LEAN_LDS_PAD")) : 0;   // diagnostic: fewer resident lean decode workgroups
     int dbg_count[2] = {0, 0};          // workgroups stamped by the last encode / decode launch
     PinBuf h_descs, h_descs_dec, h_out, h_dec;      // compress and decompress batches may be in flight together: nothing pinned is shared
-    int max_dyn_lds[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
+    int max_dyn_lds[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // largest dynamic LDS already enabled for encode (lz4) / decode / lean decode / encode (blosclz) / encode (zstd) / decode (zstd), one and two waves per block
     bool timing = false;              // events around the kernels of the current batch call
     int timing_period = 0;            // 0 = off, n = every n-th batch call is timed
     int64_t batch_no[2] = {0, 0};     // compress / decompress batch calls since timing was switched on
@@ -712,15 +721,17 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
     if ((rc = e->reserve(e->next_item, sizeof(int32_t) * ((size_t)plan.total_blocks * (size_t)(plan.cp.streams_per_block + 1) + 64)))) return rc;
     for (int pass = 0; pass < 2; pass++) {
         const int split = side ? pass : 1 - pass;     // side by side: the small (unsplit) launch first
-        const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
+        int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;                     // no blocks of that kind in the batch
+        const bool rt = e->enc_rt && (plan.cp.compcode == CODEC_LZ4 || plan.cp.compcode == CODEC_LZ4HC);
+        if (rt) lds_bytes = encode_lds_bytes_rt(lds_bytes - LZ4_HASH_BYTES);   // the plane and its margin: the table lives in registers
         hipStream_t const on = (side && !split) ? e->s_side : e->stream;
         // Split launch: whole blocks as work items -- each block read from HBM ONCE instead of once per byte plane -- when
         // the geometry allows it AND the batch is large.  A block item is `typesize` times coarser than a plane item, and
         // on a small batch the coarser granularity costs more than the second read saves (HBM is a few per cent utilised;
         // measured on 4 x 4096^2 float16 = 3.2 blocks per resident wave: 537 us against 512 us; from 8 rounds on the tail
         // is noise).  CIMG_ENC_BLOCK_ITEMS=1 / 0 forces the choice.
-        bool block_items_ok = split != 0;
+        bool block_items_ok = split != 0 && !rt;    // (the register-table kernel has no registers left for planes that wait)
         if (block_items_ok)
             for (const ChunkDesc& d : plan.descs)
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items_ok = false; break; }
@@ -758,8 +769,8 @@ static int compress_launch(cimg_engine* e, const cimg_cparams* p, int32_t nchunk
                       head_next, 0, fold ? 1 : 0, (uint8_t*)d_comp, (ChunkLayout*)e->layout.p, lay_host,
                       sync + 16, sync + 16 + nslots, next_item, e->fold_gen};
         const bool blz = plan.cp.compcode == CODEC_BLOSCLZ, zst = plan.cp.compcode == CODEC_ZSTD;
-        void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : zst ? cimg_encode_streams_zstd : cimg_encode_streams;
-        const int lds_slot = blz ? 3 : zst ? 4 : 0;
+        void (*const enc_kernel)(EncodeArgs) = blz ? cimg_encode_streams_blosclz : zst ? cimg_encode_streams_zstd : rt ? cimg_encode_streams_rt : cimg_encode_streams;
+        const int lds_slot = blz ? 3 : zst ? 4 : rt ? 11 : 0;
         // persistent chains, as many as are resident at once and never more than there are items; ganged into workgroups so
         // that the 1280-byte LDS granules of a CU come out even (encode_gang above)
         if (e->enc_wgs_lds[split] != lds_bytes || e->enc_wgs_codec != plan.cp.compcode) {

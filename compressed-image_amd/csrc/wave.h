@@ -96,6 +96,8 @@ inline int wave_simd() { return 0; }
 inline void wave_priority(int) {}
 inline void wave_sleep64(int) {}
 template <class T> inline void writelane(LV<T>& x, int lane, T value) { x.v[lane & 63] = value; }
+// lane `lane` of x becomes the wave-uniform `value` (v_writelane_b32)
+template <class T> inline void setlane(LV<T>& x, int lane, T value) { x.v[lane & 63] = value; }
 template <class T> inline void lane_gather(const LV<T>& x, const LV<int>& idx, LV<T>& out)
 {
     T tmp[64];
@@ -237,6 +239,14 @@ template <class T> CIMG_DEV void writelane(LV<T>& x, int lane, T value)
 {
     static_assert(sizeof(T) == 4, "writelane moves one dword");
     x.v = ((int)__lane_id() == lane) ? value : x.v;
+}
+// lane `lane` of x becomes the wave-uniform `value`: ONE v_writelane_b32 (the select form above is a compare + a conditional move
+// and needs the lane id in a register); the builtin has no clang spelling in ROCm 7.2, the intrinsic is reached by its name
+__device__ int cimg_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+template <class T> CIMG_DEV void setlane(LV<T>& x, int lane, T value)
+{
+    static_assert(sizeof(T) == 4, "setlane moves one dword");
+    x.v = (T)cimg_writelane_i32((int)value, lane, (int)x.v);
 }
 // out[l] = x[idx[l]] (ds_bpermute: LDS crossbar, no memory access)
 template <class T> CIMG_DEV void lane_gather(const LV<T>& x, const LV<int>& idx, LV<T>& out)

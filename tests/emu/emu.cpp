@@ -32,6 +32,7 @@ static int g_emu_zstd_plan_cap = -1;    // -1: the block area (the engine's defa
 static long g_emu_zstd_refused = 0;
 static int g_emu_zstd_lanes = 8;         // blocks a wave of the lane decoder takes (0: the walkers decode sequences themselves)
 static int g_emu_block_items = 1;     // tests also run the one-item-per-plane form
+static int g_emu_enc_rt = 1;          // LZ4 / LZ4HC streams through the register-table form of the encoder (the engine's default); 0: the LDS-table form
 
 extern "C" {
 
@@ -79,11 +80,13 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
     const uint32_t gen = 5;
     g_emu_folded = folded;
     for (int split = 1; split >= 0; split--) {
-        const int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
+        int lds_bytes = split ? plan.lds_split : plan.lds_unsplit;
         if (!lds_bytes) continue;
+        const bool rt = g_emu_enc_rt && (plan.cp.compcode == CODEC_LZ4 || plan.cp.compcode == CODEC_LZ4HC);
+        if (rt) lds_bytes = encode_lds_bytes_rt(lds_bytes - LZ4_HASH_BYTES);   // (as engine.hip: the plane and its margin, no table)
         std::vector<uint8_t> lds((size_t)lds_bytes + EMU_LDS_SLACK);
         std::vector<uint32_t> queue((size_t)ENC_NQ * ENC_QSTRIDE, 0), queue_next((size_t)ENC_NQ * ENC_QSTRIDE, 77);
-        bool block_items = split && g_emu_block_items;
+        bool block_items = split && g_emu_block_items && !rt;
         if (block_items)
             for (const ChunkDesc& d : plan.descs)
                 if (!d.memcpyed && d.split && !encode_block_items_ok(plan.cp.typesize, plan.cp.filter, d.blocksize)) { block_items = false; break; }
@@ -106,6 +109,7 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
             memset(lds.data(), 0xCD, lds.size());
             if (plan.cp.compcode == CODEC_BLOSCLZ) { EncodeStream<CODEC_BLOSCLZ> es(&ea, lds.data(), w); es.run(); }
             else if (plan.cp.compcode == CODEC_ZSTD) { EncodeStream<CODEC_ZSTD> es(&ea, lds.data(), w); es.run(); }
+            else if (rt) { EncodeStream<CODEC_LZ4_RT> es(&ea, lds.data(), w); es.run(); }
             else { EncodeStream<CODEC_LZ4> es(&ea, lds.data(), w); es.run(); }
         }
         for (int q = 0; q < ENC_NQ; q++) if (queue_next[(size_t)q * ENC_QSTRIDE] != 0) return -1;   // the next launch's heads were zeroed
@@ -123,6 +127,7 @@ int emu_compress_batch(const EmuCParams* p, int nchunks, const uint8_t* raw, con
 }
 
 extern "C" void emu_set_block_items(int on) { g_emu_block_items = on; }
+extern "C" void emu_set_enc_rt(int on) { g_emu_enc_rt = on; }
 int g_emu_lean_shape = -1;      // <= 0: rotate the number of persistent lean waves (1, 3, 7, one per block), else that many
 extern "C" void emu_set_lean_shape(int shape) { g_emu_lean_shape = shape; }
 int g_emu_lean = 1;            // tests switch the lean kernel off to cover the general one on every block
@@ -293,10 +298,16 @@ int emu_deinterleave(const uint8_t* src, int nch, int ts, int64_t npixels, uint8
 // single-stream entry points for the LZ4 wave codec
 int emu_lz4_encode(const uint8_t* src, int n, uint8_t* dst, int cap, int accel, int* need)
 {
-    std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
-    memcpy(lds.data(), src, (size_t)n);
-    int nd = 0;
-    const int r = lz4_encode_wave(lds.data(), 0, round16(n), n, dst, cap, accel, &nd);
+    int nd = 0, r;
+    if (g_emu_enc_rt) {     // the register-table form: the LDS holds the plane and its margin (exactly the launch size)
+        std::vector<uint8_t> lds((size_t)encode_lds_bytes_rt(n) + EMU_LDS_SLACK, 0xCD);
+        memcpy(lds.data(), src, (size_t)n);
+        r = lz4_encode_rt_body(lds.data(), n, dst, cap, accel, nd);
+    } else {
+        std::vector<uint8_t> lds((size_t)round16(n) + 64 + LZ4_HASH_BYTES, 0xCD);
+        memcpy(lds.data(), src, (size_t)n);
+        r = lz4_encode_wave(lds.data(), 0, round16(n), n, dst, cap, accel, &nd);
+    }
     if (need) *need = nd;
     return r;
 }
