@@ -420,6 +420,8 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
         int pre = 0;        // 1: lane 0 is the probe right after a match (position sstart - 1)
         LV<uint32_t> Wn;    // bytes [ip - 2, ip + 10) around the end of the last match, lanes 0..2 (scalar head)
         FOR_LANES(l) { Wn[l] = 0; }
+        [[maybe_unused]] int chain_credit = 2;   // zero-literal chain below: tried while it pays -- a score in [-8, 8], + 3 for a zero-literal sequence, - 2 for a
+                                // miss of the chain's first probe or (while the chain is off) a sequence with literals; the chain runs above 0
         int guard = 0;      // every wave must reach an exit: a window commits at least one probe, a head iteration finds a match (>= 4 bytes)
                             // or is followed by a window, so 2 n + 4 iterations is a hard bound
         // ONE way out of the loop: every exit is a `break` with `ending` saying why.  With returns inside the loop the compiler
@@ -557,6 +559,10 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);               // match extension
             ip -= backrun; mp -= backrun; mcode += backrun;
             const int lit = zero_lit ? 0 : ip - anchor;
+            // (the zero-literal chain pays above ~40 % hits of the post-match probe: the score follows that rate whether or not the chain runs)
+#ifdef CIMG_ZERO_LIT_CHAIN
+            chain_credit = zero_lit ? imin(chain_credit + 3, 8) : imax(chain_credit - (chain_credit > 0 ? 0 : 2), -8);
+#endif
             // the ten bytes the scalar head of the NEXT search needs sit at the end of this match: request them now, so
             // that the LDS round trip runs behind the bookkeeping below instead of in front of the next search
             FOR_LANES(l) { Wn[l] = lds_ld32u(in, ip + mcode + 4 - 2 + 4 * (l < 2 ? l : 2)); }
@@ -596,6 +602,91 @@ CIMG_DEV int lz4_encode_body(const uint8_t* in, uint8_t* tab, int n, uint8_t* ou
             if (pre && t0 == 0 && s64 == 64)                      // (every sequence leaves pre == 1, t0 == 0: only the range is tested again)
             while (mflimit_p1 - sstart >= 3) {
                 if (++guard > 2 * n + 4) { ending = -1; stop = true; break; }
+#ifdef CIMG_ZERO_LIT_CHAIN   /* measured: the chain itself runs a sequence in ~900 cycles against ~1600 through the head, but launches got no faster (LABNOTES.md, round 5) */
+                // ---- zero-literal chain (round 5) -------------------------------------------------------------------------------
+                // On sequence-dense data -- photographs -- the probe right after a match is the next match 60 - 95 % of the time (a
+                // zero-literal sequence).  That case gets a loop of its own with nothing in it that it does not need: the refill, ONE
+                // slot, the candidate's 256 bytes against the 256 bytes at the probe in one round trip (the comparison and the whole
+                // extension: no literals, nothing backwards), the sequence parked.  The ten bytes the next turn starts from are the
+                // bytes just compared, still in registers (no round trip for them).  About 75 instructions and two LDS round trips a
+                // sequence against ~185 and four through the head below.  A miss leaves the table as it found it but for the refill
+                // (which the head writes again: same slot, same value) and drops into the head.
+                if (chain_credit > 0) {
+                    int chained = 0;
+                    CIMG_PROF_LAP(1);
+                    uint32_t cw0 = readlane(Wn, 0), cw1 = readlane(Wn, 1);          // bytes [ip - 2, ip + 2), [ip + 2, ip + 6)
+                    for (;;) {
+                        if (mflimit_p1 - sstart < 3) break;                       // the last bytes of a plane go through the general paths
+                        if (++guard > 2 * n + 4) { ending = -1; stop = true; break; }
+                        const int ip0 = sstart - 1;
+                        const uint32_t v0 = (cw0 >> 16) | (cw1 << 16);
+                        const uint32_t h0 = lz4_hash<HB>(v0);
+                        FOR_LANES_W(l) { tab16[lz4_hash<HB>(cw0)] = (uint16_t)(sstart - 3); }   // the "put(ip - 2)" refill
+                        LV<uint32_t> slot;
+                        FOR_LANES(l) { slot[l] = tab16[h0]; }
+                        const int c0 = (int)readlane(slot, 0);
+                        LV<uint32_t> cw, iw;
+                        FOR_LANES(l) {
+                            cw[l] = lds_ld32u(in, c0 + 4 * l);
+                            iw[l] = lds_ld32u(in, ip0 + 4 * l);
+                        }
+                        needed_here(cw); needed_here(iw);                       // (one round trip: without this the bytes at the probe are loaded behind the branch)
+                        if (readlane(cw, 0) != v0) { chain_credit -= chained ? 0 : 2; CIMG_PROF_LAP(0); CIMG_PROF_COUNT(4); break; }
+                        FOR_LANES_W(l) { tab16[h0] = (uint16_t)ip0; }
+                        CIMG_STAT(g_emu_matches);
+                        const int maxc = matchlimit - (ip0 + 4);
+                        LV<int> len;
+                        LV<bool> stopl;
+                        FOR_LANES(l) {
+                            const int k = 4 * (l - 1);                              // lane 0 holds the four matched bytes
+                            const uint32_t x = cw[l] ^ iw[l];
+                            const int ln = imin(x ? (int)(__builtin_ctz(x) >> 3) : 4, imax(maxc - k, 0));
+                            len[l] = ln;
+                            stopl[l] = (l >= 1) & (ln < 4);
+                        }
+                        const uint64_t sm = ballot(stopl);
+                        int mc;
+                        if (sm) { const int f = ctz64(sm); mc = 4 * (f - 1) + readlane(len, f); }
+                        else mc = match_more(in, ip0, c0, maxc, 252, n);
+                        // park the sequence (no literals)
+                        setlane(P_anchor, np, ip0);
+                        setlane(P_lit, np, 0);
+                        setlane(P_off, np, ip0 - c0);
+                        setlane(P_mcode, np, mc);
+                        if (++np == 64) {
+                            bool fits_;
+                            if constexpr (SEQ) fits_ = zstd_take_parked(in, out, cap, op, *sink, np, P_anchor, P_lit, P_off, P_mcode);
+                            else fits_ = emit_pending(in, out, cap, op, need, np, P_anchor, P_lit, P_off, P_mcode);
+                            if (!fits_) { ending = 0; stop = true; break; }
+                            np = 0;
+                        }
+                        const int d = mc + 4;                                       // the match covers [ip0, ip0 + d)
+                        CIMG_PROF_LAP(7); CIMG_PROF_COUNT(7);
+                        anchor = ip0 + d;
+                        chained = 1;
+                        chain_credit = imin(chain_credit + 3, 8);
+                        if (anchor >= mflimit_p1) { stop = true; break; }           // the plane is finished (ending stays 1)
+                        sstart = anchor + 1;
+                        // the bytes around the end of the match, from the dwords just compared (iw[k] = bytes [ip0 + 4 k, + 4))
+                        if (d <= 249) {
+                            const int a = (d - 2) >> 2;
+                            const uint32_t sh = (uint32_t)(d - 2) & 3u;
+                            const uint32_t q0 = readlane(iw, a), q1 = readlane(iw, a + 1), q2 = readlane(iw, a + 2);
+                            cw0 = alignbyte(q1, q0, sh);
+                            cw1 = alignbyte(q2, q1, sh);
+                        } else {
+                            LV<uint32_t> far;
+                            FOR_LANES(l) { far[l] = lds_ld32u(in, anchor - 2 + 4 * (l < 2 ? l : 2)); }
+                            cw0 = readlane(far, 0); cw1 = readlane(far, 1);
+                        }
+                    }
+                    if (stop) break;
+                    if (chained) {                                              // the head below reads its ten bytes from Wn
+                        if (mflimit_p1 - sstart < 3) break;                     // (what the head's own loop condition says)
+                        FOR_LANES(l) { Wn[l] = lds_ld32u(in, anchor - 2 + 4 * (l < 2 ? l : 2)); }
+                    }
+                }
+#endif
                 const int ip0 = sstart - 1;
                 const uint32_t w0 = readlane(Wn, 0), w1 = readlane(Wn, 1);     // requested when the previous match was parked
                 const uint32_t v0 = (w0 >> 16) | (w1 << 16), v1 = (w0 >> 24) | (w1 << 8), v2 = w1;   // bytes at ip0, ip0 + 1, ip0 + 2

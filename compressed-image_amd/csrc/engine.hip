@@ -259,7 +259,7 @@ struct cimg_engine {
     int enc_waves_cu = 1;               // encode waves per CU the registers allow (occupancy query, cached with enc_wgs_lds)
     int lds_per_cu = 163840, lds_per_wg = 65536;      // device properties
     int enc_gang = getenv("CIMG_ENC_GANG") ? atoi(getenv("CIMG_ENC_GANG")) : 0;
-    int enc_rt = getenv("CIMG_ENC_RT") ? atoi(getenv("CIMG_ENC_RT")) : 1;   // LZ4 / LZ4HC: the encoder with its hash table in registers (encode_rt_kernel.h); 0: the LDS-table form
+    int enc_rt = getenv("CIMG_ENC_RT") ? atoi(getenv("CIMG_ENC_RT")) : 0;   // LZ4 / LZ4HC: the encoder with its hash table in registers (encode_rt_kernel.h; experimental: measured slower, LABNOTES.md); 0: the LDS-table form
     int enc_said_lds = -1, enc_said_gang = -1;
     int enc_wgs_lds[2] = {-1, -1};
     int enc_wgs_codec = -1;

@@ -112,6 +112,12 @@ def lean_blocks():
     return int(lib().emu_lean_blocks())
 
 
+def set_enc_rt(on):
+    """1: LZ4 streams through the register-table form of the encoder (csrc/encode_rt_kernel.h), 0: the LDS-table form (default)."""
+    lib().emu_set_enc_rt.argtypes = [C.c_int]
+    lib().emu_set_enc_rt(int(on))
+
+
 def lz4_encode(src, cap=None, accel=1):
     s = _u8(src)
     n = s.size

@@ -32,7 +32,7 @@ static int g_emu_zstd_plan_cap = -1;    // -1: the block area (the engine's defa
 static long g_emu_zstd_refused = 0;
 static int g_emu_zstd_lanes = 8;         // blocks a wave of the lane decoder takes (0: the walkers decode sequences themselves)
 static int g_emu_block_items = 1;     // tests also run the one-item-per-plane form
-static int g_emu_enc_rt = 1;          // LZ4 / LZ4HC streams through the register-table form of the encoder (the engine's default); 0: the LDS-table form
+static int g_emu_enc_rt = 0;          // LZ4 / LZ4HC streams through the register-table form of the encoder (CIMG_ENC_RT=1); 0: the LDS-table form, the engine's default
 
 extern "C" {
 

@@ -40,6 +40,59 @@ def test_wave_lz4_encoder_matches_liblz4(kat, order):
         E.set_write_order(0)
 
 
+def _dense_streams(seed, count):
+    """Sequence-dense streams (what photographs shuffle into): tiny alphabets, slow ramps, sparse noise, periodic rows with
+    mutations, smooth 2-D gradients -- the post-match probe hits on most sequences, searches of 2 .. 20 probes on the rest."""
+    rng = np.random.default_rng(seed)
+    for i in range(count):
+        n = int(rng.integers(13, 33000)) if i % 7 else int(rng.choice([13, 14, 64, 77, 4096, 16384, 32768]))
+        kind = i % 6
+        if kind == 0:
+            s = rng.integers(0, int(rng.integers(2, 6)), n)
+        elif kind == 1:
+            s = np.cumsum(rng.integers(0, 2, n)) // int(rng.integers(1, 4))
+        elif kind == 2:
+            s = rng.integers(0, 256, n) * (rng.random(n) < rng.choice([0.05, 0.3]))
+        elif kind == 3:
+            row = rng.integers(0, 256, int(rng.integers(5, 300)))
+            s = np.resize(row, n).copy()
+            flips = rng.integers(0, n, max(1, n // int(rng.integers(20, 400))))
+            s[flips] = rng.integers(0, 256, flips.size)
+        elif kind == 4:
+            w = int(rng.integers(16, 512))
+            y, x = np.divmod(np.arange(n), w)
+            s = (np.sin(x / 37.0) * 40 + np.cos(y / 11.0) * 30 + 128).astype(np.int64) + (rng.random(n) < 0.1) * rng.integers(0, 3, n)
+        else:
+            s = np.repeat(rng.integers(0, 256, n // 3 + 1), rng.integers(1, 9, n // 3 + 1))[:n]
+            if s.size < n:
+                s = np.resize(s, n)
+        yield (s.astype(np.int64) & 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("rt", [0, 1])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_dense_streams_match_liblz4_pinned_oracle(rt, order):
+    """Both forms of the LZ4 encoder (LDS table with its zero-literal chain / head / windows; register table) against the oracle
+    (pinned to liblz4 by tests/test_oracle_lz4.py) on sequence-dense streams: bytes, return value and `need`, acceleration 1 and 5,
+    capacity = the stream (c-blosc2's call) and a capacity that cuts the stream off."""
+    E.set_write_order(order)
+    E.set_enc_rt(rt)
+    try:
+        for k, src in enumerate(_dense_streams(1000 + order, 70)):
+            for accel in ((1, 5) if k % 5 == 0 else (1,)):
+                want_r, want, want_need = O.lz4_compress(src, cap=src.size, accel=accel, want_need=True)
+                r, out, need = E.lz4_encode(src, src.size, accel)
+                assert r == want_r, (k, src.size, accel)
+                assert out == want[:max(want_r, 0)], (k, src.size, accel)
+                if want_r > 0:
+                    assert need == want_need, (k, src.size, accel)
+                    cut = max(1, want_need - 1 - (k % 9))             # one short of what the encoder needs: both say 0
+                    assert E.lz4_encode(src, cut, accel)[0] == O.lz4_compress(src, cap=cut, accel=accel)[0] == 0, (k, cut)
+    finally:
+        E.set_write_order(0)
+        E.set_enc_rt(0)
+
+
 def test_noise_planes_match_the_oracle():
     """Noise planes go through the no-match walk of the encoder; one in forty has a table slot that three probes of a window
     share, one in eighty a real four-byte repeat that LZ4 finds -- both hand the plane to the full encoder.  Same verdict, same
