@@ -316,6 +316,34 @@ def run_config1(args, rank, world, local_rank, dist, red_dev):
                "roofline_decode": {"kernel": "cimg_decode_lean + cimg_decode_blocks", "bound": "hbm", "median_launch_us": round(d_us, 2),
                                    "achieved": round((N + Cb) / (d_us * 1e-6) / 1e9, 1) if d_us else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": round((N + Cb) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if d_us else None}}
+        if args.family == "tiled" and world == 1:
+            # configs[0] as named is incompressible (four noise bits a byte: the chunk comes out memcpyed, ratio 1.000): a second leg on
+            # the natural family, where the codec actually codes -- same calls, same geometry
+            nat = synth.natural_channel(np.uint8, W, H).view(np.uint8).ravel()
+            d_raw.copy_(torch.from_numpy(nat).cuda())
+            ncb = step().copy()
+            okn = torch.equal(d_out, d_raw)
+            rn, wantn = O.compress(po, nat, destsize=CHUNK + 32)
+            same_n = int(ncb[0]) == rn and d_comp[:rn].cpu().numpy().tobytes() == wantn
+            for _ in range(args.warmup):
+                step()
+            eng.enable_timing(1); eng.reset_timing()
+            torch.cuda.synchronize()
+            tn = time.perf_counter()
+            nsteps = max(20, args.steps // 4)
+            for _ in range(nsteps):
+                step()
+            torch.cuda.synchronize()
+            tn = time.perf_counter() - tn
+            ne, nd = eng.kernel_samples(hip.K_ENCODE) * 1e3, eng.kernel_samples(hip.K_DECODE) * 1e3
+            eng.enable_timing(False)
+            out["compressible"] = {"what": "the same single-chunk round trip on the natural family (the tiled uint8 chunk is memcpyed)", "family": "natural",
+                                   "value": round(nsteps * 2 * N / tn / 1e9, 3), "unit": "GB/s", "us_per_chunk_roundtrip": round(tn / nsteps * 1e6, 1),
+                                   "compression_ratio": round(N / int(ncb[0]), 4), "encode_us": round(_median(ne.tolist()), 1), "decode_us": round(_median(nd.tolist()), 1),
+                                   "bytes_equal_oracle": bool(same_n), "pixels_verified": bool(okn)}
+            if not args.no_cpu_baseline:
+                out["compressible"]["cpu_baseline"] = cpu_baseline(nat, budget_s=3.0, policy="blocks16", typesize=1, compcode=po.compcode, chunk=N, filt=filt, destsize=CHUNK + 32)
+            d_raw.copy_(torch.from_numpy(host).cuda())
         if not args.no_cpu_baseline and world == 1:
             # the reference's own call: one thread team over the blocks of the one chunk (channel.h:127: hw / 2 threads) for compression,
             # ONE thread for decompression (wrapper.h:406)
@@ -356,55 +384,64 @@ def run_config3(args, rank, world, local_rank, dist, red_dev):
     raw_off = np.arange(nchunks, dtype=np.int64) * CHUNK
     comp_off = np.arange(nchunks, dtype=np.int64) * stride
     eng = hip.Engine(local_rank)
-    filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[filt_name]
     compcode = hip.BLOSCLZ if codec == "blosclz" else hip.LZ4
-    p = hip.cparams(2, clevel=9, blocksize=BLOCK, compcode=compcode, filters=(0, 0, 0, 0, 0, filt))
-    cb0 = eng.compress_device(p, d_raw.data_ptr(), raw_off, [CHUNK] * nchunks, d_comp.data_ptr(), comp_off, [CHUNK + 32] * nchunks)   # the channels as the constructor leaves them
     perm = np.random.default_rng(99).permutation(nchunks)
-    get_chunk, set_chunk = eng.single_chunk_calls(p, d_work.data_ptr(), d_comp.data_ptr(), comp_off, CHUNK, CHUNK + 32, BLOCK)
-    work16 = d_work.view(torch.int16)                               # (+ 1 wraps the same way for int16 and uint16 bit patterns)
     ext = torch.cuda.ExternalStream(eng.stream_handle(), device=torch.device("cuda", local_rank))
-    sizes = np.asarray(cb0, np.int64).copy()
+    work16 = d_work.view(torch.int16)                               # (+ 1 wraps the same way for int16 and uint16 bit patterns)
 
-    def one_pass():
-        with torch.cuda.stream(ext):
-            for i in perm:
-                get_chunk(int(i))
-                work16.add_(1)                                      # on the engine's stream: the compress batch behind it sees the result
-                sizes[i] = set_chunk(int(i))
+    def leg(filt_name, steps, warmup, synced):
+        """the loop with one filter: the channels compressed as the constructor leaves them, `warmup` + `steps` passes over the permutation,
+        then everything decoded in one batch and compared with pixels + passes"""
+        filt = {"shuffle": hip.SHUFFLE, "bitshuffle": hip.BITSHUFFLE, "none": 0}[filt_name]
+        p = hip.cparams(2, clevel=9, blocksize=BLOCK, compcode=compcode, filters=(0, 0, 0, 0, 0, filt))
+        cb0 = eng.compress_device(p, d_raw.data_ptr(), raw_off, [CHUNK] * nchunks, d_comp.data_ptr(), comp_off, [CHUNK + 32] * nchunks)
+        get_chunk, set_chunk = eng.single_chunk_calls(p, d_work.data_ptr(), d_comp.data_ptr(), comp_off, CHUNK, CHUNK + 32, BLOCK)
+        sizes = np.asarray(cb0, np.int64).copy()
 
-    passes_done = 0
-    for _ in range(max(args.warmup, 1)):
-        one_pass(); passes_done += 1
-    eng.enable_timing(1)
-    eng.reset_timing()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    per_step = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        one_pass(); passes_done += 1
-        per_step.append(time.perf_counter() - ts)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    enc = eng.kernel_samples(hip.K_ENCODE) * 1e3
-    dec = eng.kernel_samples(hip.K_DECODE) * 1e3
-    eng.enable_timing(False)
-    # every pixel went up by one per pass: decode everything in one batch and compare
-    d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
-    eng.decompress_device(d_comp.data_ptr(), comp_off, [CHUNK] * nchunks, [BLOCK] * nchunks, d_out.data_ptr(), raw_off)
-    want = (host.view(np.uint16) + np.uint16(passes_done)).view(np.uint8)
-    if d_out.cpu().numpy().tobytes() != want.tobytes():
-        print("bench.py --config 3: the channels do not hold pixels + passes after the loop", file=sys.stderr)
-        sys.exit(3)
+        def one_pass():
+            with torch.cuda.stream(ext):
+                for i in perm:
+                    get_chunk(int(i))
+                    work16.add_(1)                                  # on the engine's stream: the compress batch behind it sees the result
+                    sizes[i] = set_chunk(int(i))
+
+        passes_done = 0
+        for _ in range(max(warmup, 1)):
+            one_pass(); passes_done += 1
+        eng.enable_timing(1)
+        eng.reset_timing()
+        if synced and dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        per_step = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts = time.perf_counter()
+            one_pass(); passes_done += 1
+            per_step.append(time.perf_counter() - ts)
+        torch.cuda.synchronize()
+        if synced and dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if synced and dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        enc = eng.kernel_samples(hip.K_ENCODE) * 1e3
+        dec = eng.kernel_samples(hip.K_DECODE) * 1e3
+        eng.enable_timing(False)
+        # every pixel went up by one per pass: decode everything in one batch and compare
+        d_out = torch.zeros(N, dtype=torch.uint8, device="cuda")
+        eng.decompress_device(d_comp.data_ptr(), comp_off, [CHUNK] * nchunks, [BLOCK] * nchunks, d_out.data_ptr(), raw_off)
+        want = (host.view(np.uint16) + np.uint16(passes_done)).view(np.uint8)
+        if d_out.cpu().numpy().tobytes() != want.tobytes():
+            print(f"bench.py --config 3 ({filt_name}): the channels do not hold pixels + passes after the loop", file=sys.stderr)
+            sys.exit(3)
+        del d_out
+        return {"elapsed": elapsed, "per_step": per_step, "enc": enc, "dec": dec, "sizes": sizes, "filt": filt}
+
+    main_leg = leg(filt_name, args.steps, args.warmup, True)
+    elapsed, per_step, enc, dec, sizes, filt = (main_leg[k] for k in ("elapsed", "per_step", "enc", "dec", "sizes", "filt"))
     visits = args.steps * nchunks
     Cb = float(sizes.sum())
     if rank == 0:
@@ -430,6 +467,18 @@ def run_config3(args, rank, world, local_rank, dist, red_dev):
                "roofline_decode": {"kernel": "cimg_decode_lean + cimg_decode_blocks", "bound": "hbm", "median_launch_us": round(d_us, 2),
                                    "achieved": round((CHUNK + cmean) / (d_us * 1e-6) / 1e9, 1) if d_us else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                    "frac": round((CHUNK + cmean) / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5) if d_us else None}}
+        if filt_name == "bitshuffle" and codec == "blosclz" and args.family == "tiled" and world == 1:
+            # configs[2] as named comes out memcpyed (BloscLZ 2.3.0 gives up on the noise bit rows: ratio 1.000): one pass of the same
+            # loop with BYTE shuffle, where the codec actually codes
+            cl = leg("shuffle", 1, 1, False)
+            ce, cd = _median(cl["enc"].tolist()), _median(cl["dec"].tolist())
+            out["compressible"] = {"what": "one pass of the same loop with byte shuffle (the reference's filter) instead of bitshuffle", "filter": "byte shuffle",
+                                   "value": round(nchunks * 2 * CHUNK / cl["elapsed"] / 1e9, 3), "unit": "GB/s",
+                                   "us_per_chunk_visit": round(cl["elapsed"] / nchunks * 1e6, 1), "compression_ratio": round(N / float(cl["sizes"].sum()), 4),
+                                   "encode_us": round(ce, 1), "decode_us": round(cd, 1), "pixels_verified": True}
+            if not args.no_cpu_baseline:
+                out["compressible"]["cpu_baseline"] = cpu_random_access(host, perm, compcode=O.BLOSCLZ, filt=hip.SHUFFLE, budget_s=5.0,
+                                                                        cthreads=min(visible_cores(), 16), dthreads=min(visible_cores(), 16))
         if not args.no_cpu_baseline and world == 1:
             # the same loop on the host: the reference's call structure (one chunk at a time; compression with hw / 2 threads over the
             # chunk's blocks, channel.h:127; decompression on one thread, wrapper.h:406; the + 1 in numpy) on a bounded sample of chunks
@@ -889,7 +938,7 @@ def main():
         sys.exit(3)
 
     # ---- a measured copy peak beside the 8 TB/s specification, and the OTHER face of the codec (natural family) in the same line ----
-    copy_peak = natural = None
+    copy_peak = natural = dtypes = None
     headline = args.family == "tiled" and args.filter == "shuffle" and args.codec == "lz4" and args.config == 2 and not strong
     if rank == 0:
         copy_peak = measure_copy_peak()
@@ -913,6 +962,37 @@ def main():
                            f"{nsteps} steps outside the timed region", "value": round(nsteps * 2 * N / tn / 1e9, 3), "unit": "GB/s",
                    "encode_us": round(float(np.median(ne)) * 1e3, 1) if len(ne) else None, "decode_us": round(float(np.median(nd)) * 1e3, 1) if len(nd) else None,
                    "compression_ratio": round(N / float(ncb.sum()), 4), "pixels_verified": bool(ok)}
+        if not args.no_cpu_baseline:
+            # the CPU beside the GPU on the HARD data too: the same 16-thread port over the same natural chunks
+            natural["cpu_baseline"] = cpu_baseline(nat, budget_s=5.0, policy="share")
+            natural["gpu_over_cpu"] = round(natural["value"] / natural["cpu_baseline"]["value"], 2)
+        # configs[1]'s geometry on the pixel types north_star names beside float16 (two steps each, outside the timed region):
+        # byte-wide photographs -- ONE 32 KiB stream a block, three chains a CU -- and tiled float32, configs[4]'s element type
+        dtypes = {}
+        for dt_name, fam in (("uint8", "natural"), ("float32", "tiled")):
+            dt = np.dtype(dt_name)
+            pix = np.ascontiguousarray(getattr(synth, fam + "_channel")(dt.type, WIDTH, N // (WIDTH * dt.itemsize))).view(np.uint8).ravel()
+            d_raw.copy_(torch.from_numpy(pix).cuda())
+            pd = hip.cparams(dt.itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4, filters=(0, 0, 0, 0, 0, hip.SHUFFLE))
+            def dstep():
+                cb_ = eng.compress_device(pd, d_raw.data_ptr(), raw_off, nbytes, d_comp.data_ptr(), comp_off, destsize)
+                eng.decompress_device(d_comp.data_ptr(), comp_off, nbytes, blocksize, d_out.data_ptr(), raw_off, comp_size=cb_)
+                return cb_
+            dstep()
+            d_out.zero_()
+            torch.cuda.synchronize()
+            eng.enable_timing(1); eng.reset_timing()
+            td = time.perf_counter()
+            for _ in range(2):
+                dcb = dstep()
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            de, dd = eng.kernel_samples(hip.K_ENCODE), eng.kernel_samples(hip.K_DECODE)
+            eng.enable_timing(False)
+            dtypes[f"{dt_name}_{fam}"] = {"value": round(2 * 2 * N / td / 1e9, 3), "unit": "GB/s (compress + decompress, uncompressed side, plain calls)",
+                                          "encode_us": round(float(np.median(de)) * 1e3, 1) if len(de) else None,
+                                          "decode_us": round(float(np.median(dd)) * 1e3, 1) if len(dd) else None,
+                                          "compression_ratio": round(N / float(np.asarray(dcb).sum()), 4), "pixels_verified": bool(torch.equal(d_out, d_raw))}
         d_raw.copy_(torch.from_numpy(host).cuda())
         torch.cuda.synchronize()
 
@@ -979,6 +1059,7 @@ def main():
                                 "frac_of_measured_peak": round((Cb + N) / dec_avg_s / 1e9 / copy_peak, 4) if dec_avg_s > 0 and copy_peak else None},
             "kernels": kernels,
             "natural_family": natural,
+            "dtypes": dtypes,
             "last_step_verified": "d_out cleared in front of the last timed step, pixels compared with the input after it",
             "exchange": exchange,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",

@@ -249,7 +249,8 @@ struct cimg_engine {
     int64_t zstd_blocks_refused = 0;    // blocks whose plan did not fit its slot (decoded by cimg_decode_zstd behind the two launches)
     int zstd_fused = getenv("CIMG_ZSTD_FUSED") ? atoi(getenv("CIMG_ZSTD_FUSED")) : 0;          // 1: cimg_decode_zstd only (no walk / replay launches)
     int zstd_plan_cap = getenv("CIMG_ZSTD_PLAN_CAP") ? atoi(getenv("CIMG_ZSTD_PLAN_CAP")) : 0;   // diagnostic: bytes of records / literals a plan may take (0: the block area)
-    int64_t zstd_plan_bytes = getenv("CIMG_ZSTD_PLAN_MIB") ? atoll(getenv("CIMG_ZSTD_PLAN_MIB")) << 20 : 2048ll << 20;   // plans of one pair of launches (larger batches: in groups)
+    int64_t zstd_plan_bytes = getenv("CIMG_ZSTD_PLAN_MIB") ? atoll(getenv("CIMG_ZSTD_PLAN_MIB")) << 20 : 512ll << 20;   // device memory for the plans of one group of launches (a plan is ~4.25 x its block: 139 KB for 32 KiB; larger batches go in groups; round 4 took up to 2 GiB and kept it: ADVICE r4)
+    bool zstd_plan_fail = getenv("CIMG_ZSTD_PLAN_FAIL") != nullptr;   // test hook: the plans' device memory cannot be had (the fused kernel reads the batch)
     int zstd_walk_stage = getenv("CIMG_ZSTD_WALK_STAGE") ? atoi(getenv("CIMG_ZSTD_WALK_STAGE")) : 2048;   // bytes of LDS through which a walker reads a frame's sections (measured on 128 MiB of level-22 float32: 8192 = 8 waves a CU 2.51 ms, 4096 = 10 waves 2.45, 2048 = 11 waves 2.28 -- a section that does not fit is read where it lies)
     int zstd_lanes = getenv("CIMG_ZSTD_LANES") ? atoi(getenv("CIMG_ZSTD_LANES")) : 8;   // blocks a wave of cimg_zstd_seq decodes side by side (0: the walkers decode sequences themselves)
     DevBuf zplan;
@@ -1107,8 +1108,19 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
             const int cap = e->zstd_plan_cap > 0 ? e->zstd_plan_cap : area;
             const int lanes = std::max(0, std::min(e->zstd_lanes, std::min(64, (e->lds_per_wg - 64 - (int)ZSTD_SEQ_CODES_BYTES) / (int)ZSTD_SEQ_LANE_BYTES)));
             const int64_t stride = zstd_plan_stride(cap, lanes > 0);
-            const int group = (int)std::max<int64_t>(1, std::min<int64_t>(plan.total_blocks, e->zstd_plan_bytes / stride));
-            if ((rc = e->reserve(e->zplan, (size_t)group * (size_t)stride))) return rc;
+            int group = (int)std::max<int64_t>(1, std::min<int64_t>(plan.total_blocks, e->zstd_plan_bytes / stride));
+            // the plans are a convenience, not a requirement: when the device cannot spare the memory the groups shrink, and below
+            // 64 blocks a group the fused kernel -- which needs no plan -- reads everything
+            while ((rc = e->zstd_plan_fail ? -4 /* BLOSC2_ERROR_MEMORY_ALLOC */ : e->reserve(e->zplan, (size_t)group * (size_t)stride))) {
+                (void)hipGetLastError();
+                if (group <= 64) break;
+                group /= 2;
+            }
+            if (rc) {
+                if (e->verbose) fprintf(stderr, "[cimg] zstd: no device memory for plans (%lld bytes a block): cimg_decode_zstd reads the batch\n", (long long)stride);
+                if ((rc = fused(zb, 0, plan.total_blocks))) return rc;
+                return 0;
+            }
             volatile uint32_t* refused = skipped_host;           // (the lean launch's words have been read: the first one counts refused plans now)
             zb.skipped = (uint32_t*)((uint8_t*)da.status + ((f.st_bytes + 15) & ~(size_t)15));
             zb.zplan = (uint8_t*)e->zplan.p; zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.zlanes = lanes;
@@ -1119,6 +1131,10 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
             for (int g0 = 0; g0 < plan.total_blocks; g0 += group) {
                 const int nb = std::min(group, plan.total_blocks - g0);
                 *refused = 0;
+                // one word per block behind the counter: ZFALL_PENDING from the replay for a block it left to cimg_decode_zstd,
+                // ZFALL_DONE from that kernel (the lean launch's words, which lived here, have been read)
+                volatile uint32_t* const fall = refused + 1;
+                for (int b = g0; b < g0 + nb; b++) fall[b] = 0;
                 DecodeArgs wa = zb;
                 wa.blk_first = g0; wa.lds_bytes = zstd_walk_lds_bytes(e->zstd_walk_stage);
                 if ((rc = e->launch(CIMG_K_ZSTD_WALK, cimg_zstd_walk, wa, nb, 64, wa.lds_bytes))) return rc;
@@ -1145,12 +1161,24 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
                 if ((rc = e->launch(CIMG_K_ZSTD_REPLAY, cimg_zstd_replay, ra, nb, 64, ra.lds_bytes))) return rc;
                 launched = true;
                 if ((rc = cimg_engine_synchronize(e))) return rc;
-                if (*refused) {
-                    e->zstd_blocks_refused += *refused;
-                    if (e->verbose) fprintf(stderr, "[cimg] zstd: %u of %d plans did not fit their slots (cimg_decode_zstd reads those blocks)\n", (unsigned)*refused, nb);
+                // what the replay left over is read from the blocks' own words; the counter is statistics (and a second witness)
+                int pending = 0;
+                for (int b = g0; b < g0 + nb; b++) pending += fall[b] == ZFALL_PENDING;
+                if (pending || *refused) {
+                    e->zstd_blocks_refused += std::max<int64_t>(pending, *refused);
+                    if (e->verbose) fprintf(stderr, "[cimg] zstd: %d of %d plans did not fit their slots (counter: %u; cimg_decode_zstd reads those blocks)\n", pending, nb, (unsigned)*refused);
                     if (fused_fits) {
                         if ((rc = fused(zb, g0, nb))) return rc;
                         if ((rc = cimg_engine_synchronize(e))) return rc;
+                    }
+                    // a block that is still pending was decoded by nobody: its chunk fails, loudly
+                    for (int b = g0; b < g0 + nb; b++) {
+                        if (fall[b] != ZFALL_PENDING) continue;
+                        const ChunkDesc* const descs = (const ChunkDesc*)e->shadow_dec.data();   // (this batch's descriptors as uploaded)
+                        for (int i = 0; i < nchunks && e->shadow_dec.size() >= sizeof(ChunkDesc) * (size_t)nchunks; i++) {
+                            if (b >= descs[i].blk0 && b < descs[i].blk0 + descs[i].nblocks) { if (st[i] >= 0) st[i] = ERR_FAILURE; break; }
+                        }
+                        if (e->shadow_dec.size() < sizeof(ChunkDesc) * (size_t)nchunks) return e->fail(ERR_FAILURE, "zstd: block %d was left to cimg_decode_zstd and never decoded", b);
                     }
                 }
             }

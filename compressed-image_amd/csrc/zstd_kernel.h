@@ -197,6 +197,9 @@ struct DecodeZstdBlock {
             if (st == ZSTD_BLOCK_NOT_OURS) return;
             if (st < first) { first = st; code = cd; }
         }
+        // (behind the walk / replay launches: this block was left to this kernel, and the host waits to hear that it was taken --
+        // whatever became of it, which the status word says)
+        if (wv == 0 && a.zplan != nullptr && a.skipped) { FOR_LANES_W(l) { if (l == 0) a.skipped[1 + b] = 2 /* ZFALL_DONE */; } }
         if (first != ZSTD_BLOCK_FINE) { if (wv == 0) fail(chunk, code); return; }
         // the filter stage is the general kernel's own (decode_kernel.h: DecodeBlock::phase_b -- byte shuffle for every element
         // size, bit shuffle, none): the planes lie back to back here, i.e. its region stride is the plane size, and its four

@@ -17,6 +17,7 @@ namespace cimg {
 
 enum : int { ZSTD_PLAN_OPS = 62, ZSTD_PLAN_NLIT_AT = 2000, ZSTD_PLAN_JOBS_AT = 2048, ZSTD_PLAN_JOBS = 32, ZSTD_PLAN_LITJOBS_AT = 3072, ZSTD_PLAN_LITJOBS = 16, ZSTD_PLAN_HEAD = 4096,
              ZSTD_PLAN_TABLES = 4, ZSTD_PLAN_TABLE_BYTES = ZSTD_PLAN_TABLES * (ZSTD_JOB_TABLE_BYTES + ZSTD_HUF_TABLE_BYTES) };   // (tables of four compressed blocks: FSE and Huffman)
+enum : int { ZFALL_PENDING = 1, ZFALL_DONE = 2 };        // DecodeArgs::skipped[1 + block] while the read path runs: the replay left the block to cimg_decode_zstd / that kernel took it
 enum : int { ZPLAN_NOT_OURS = 0, ZPLAN_READY = 1, ZPLAN_FALLBACK = 2 };          // a plan's first word; negative: the block's error code
 static_assert(16 + ZSTD_PLAN_OPS * sizeof(ZstdOp) <= ZSTD_PLAN_NLIT_AT && ZSTD_PLAN_JOBS_AT + ZSTD_PLAN_JOBS * sizeof(ZstdSeqJob) <= ZSTD_PLAN_LITJOBS_AT &&
               ZSTD_PLAN_LITJOBS_AT + ZSTD_PLAN_LITJOBS * sizeof(ZstdLitJob) <= ZSTD_PLAN_HEAD, "status, counts, ops and jobs in the head of a slot");
@@ -104,6 +105,11 @@ struct ZstdReplayBlock {
         if (status == ZPLAN_FALLBACK) {
             // (a.tune & 2: blocks so large that cimg_decode_zstd cannot take over -- its LDS holds output AND tables: the chunk says so)
             if (a.tune & 2) fail(find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks), ERR_CODEC_SUPPORT);
+            // The block is NOT decoded yet, and says so where the host looks: its own word behind the refusal counter (page-locked
+            // host memory, as the status words are) becomes ZFALL_PENDING; cimg_decode_zstd turns it into ZFALL_DONE, and the host
+            // fails every chunk that still has a pending block when the call ends (the counter alone -- one word, bumped
+            // by an atomic across PCIe -- was all that stood between a lost count and pixels that were never written).
+            else if (a.skipped) { FOR_LANES_W(l) { if (l == 0) a.skipped[1 + b] = ZFALL_PENDING; } }
             return;
         }
         if (status != ZPLAN_READY) { fail(find_chunk(a.descs, a.nchunks, b, a.uniform_nblocks), status < 0 ? status : ERR_FAILURE); return; }

@@ -191,7 +191,8 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     // them the fused kernels for the blocks whose plan did not fit its slot -- everything, when the planner is switched off
     // (emu_set_zstd_plan: cap 0 = fused only; a small cap makes plans overflow).
     std::vector<uint8_t> zplan;
-    uint32_t refused = 0;
+    std::vector<uint32_t> fallwords((size_t)plan.total_blocks + 2, 0);   // [0]: the refusal counter, [1 + b]: block b left to / taken by the fused kernel
+    uint32_t& refused = fallwords[0];
     bool no_fused = false;
     DecodeArgs zb = da;
     zb.done = nullptr;
@@ -202,7 +203,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         const int lanes = g_emu_zstd_lanes;
         const int64_t stride = zstd_plan_stride(cap, lanes > 0);
         zplan.assign((size_t)plan.total_blocks * (size_t)stride, 0xCD);
-        zb.skipped = &refused;
+        zb.skipped = fallwords.data();
         zb.zplan = zplan.data(); zb.zplan_stride = stride; zb.zcap = cap; zb.zarea = area; zb.blk_first = 0; zb.zlanes = lanes; zb.zblocks = plan.total_blocks;
         DecodeArgs wa = zb;
         wa.lds_bytes = zstd_walk_lds_bytes();
@@ -245,7 +246,11 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
         }
         g_emu_zstd_refused += refused;
     }
-    const bool run_fused = (unread[0] || unread[1]) && (!planned || (refused > 0 && !no_fused));
+    // as the engine does: what the replay left over is read from the blocks' own words, the counter is a second witness
+    int pending = 0;
+    for (int b = 0; b < plan.total_blocks; b++) pending += fallwords[(size_t)b + 1] == ZFALL_PENDING;
+    if (planned && pending != (no_fused ? 0 : (int)refused)) return -1;           // (every refused plan is a pending block, and nothing else is)
+    const bool run_fused = (unread[0] || unread[1]) && (!planned || (pending > 0 && !no_fused));
     if (!run_fused) { unread[0] = false; unread[1] = false; }
     const bool two_waves = unread[1] && zstd_kernel_lds_bytes(max_bs, 2) <= 163840;       // (engine.hip: decompress_finish)
     if (!two_waves) { unread[0] = unread[0] || unread[1]; unread[1] = false; }
@@ -279,6 +284,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
             for (int k = 0; k < nw; k++) ws[k]->phase_b(k);
         }
     }
+    for (int b = 0; b < plan.total_blocks; b++) if (fallwords[(size_t)b + 1] == ZFALL_PENDING) return -1;   // a block nobody decoded
     return 0;
 }
 

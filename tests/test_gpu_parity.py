@@ -807,7 +807,7 @@ def test_zstd_chunks_decode_on_the_gpu(eng, golden_dir):
     L.blosc2_free_ctx(dctx)
 
 
-@pytest.mark.parametrize("form", ["lanes_8", "lanes_3", "walkers_decode_sequences", "fused", "plans_overflow", "groups_of_9_blocks"])
+@pytest.mark.parametrize("form", ["lanes_8", "lanes_3", "walkers_decode_sequences", "fused", "plans_overflow", "groups_of_9_blocks", "no_memory_for_plans"])
 def test_every_form_of_the_zstd_read_path_on_the_gpu(form, golden_dir, monkeypatch):
     """The read path of zstd chunks is several launches (engine.hip: decompress_finish -- cimg_zstd_walk, cimg_zstd_lit beside
     cimg_zstd_seq, cimg_zstd_replay) with cimg_decode_zstd behind them for blocks whose plan does not fit its slot.  Every form the
@@ -816,8 +816,9 @@ def test_every_form_of_the_zstd_read_path_on_the_gpu(form, golden_dir, monkeypat
     fails a damaged chunk by itself, and says how many plans were refused."""
     env = {"lanes_8": {}, "lanes_3": {"CIMG_ZSTD_LANES": "3"}, "walkers_decode_sequences": {"CIMG_ZSTD_LANES": "0"},
            "fused": {"CIMG_ZSTD_FUSED": "1"}, "plans_overflow": {"CIMG_ZSTD_PLAN_CAP": "256"},
-           "groups_of_9_blocks": {"CIMG_ZSTD_PLAN_MIB": "1"}}[form]            # (a batch whose plans exceed the plan memory goes in groups of blocks)
-    for k in ("CIMG_ZSTD_LANES", "CIMG_ZSTD_FUSED", "CIMG_ZSTD_PLAN_CAP", "CIMG_ZSTD_PLAN_MIB"):
+           "groups_of_9_blocks": {"CIMG_ZSTD_PLAN_MIB": "1"},                   # (a batch whose plans exceed the plan memory goes in groups of blocks)
+           "no_memory_for_plans": {"CIMG_ZSTD_PLAN_FAIL": "1"}}[form]           # (the plans' allocation fails: the fused kernel reads the batch -- ADVICE r4)
+    for k in ("CIMG_ZSTD_LANES", "CIMG_ZSTD_FUSED", "CIMG_ZSTD_PLAN_CAP", "CIMG_ZSTD_PLAN_MIB", "CIMG_ZSTD_PLAN_FAIL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
