@@ -743,19 +743,24 @@ def main():
         sys.exit(1)
     # CIMG_BENCH_REHEARSAL=1: every rank on GPU 0 over gloo -- rehearses the N > 1 control flow on a one-GPU box
     # (numbers from such a run mean nothing: the ranks share one card)
+    # CIMG_BENCH_REHEARSAL=nccl: the same, but over RCCL -- two ranks sharing one device, so that RCCL's send/recv of the exchange
+    # step has run at least once where no multi-GPU node is to be had (if RCCL accepts two ranks per device: profiles/r05/nccl_rehearsal.txt)
     rehearsal = os.environ.get("CIMG_BENCH_REHEARSAL") is not None
+    rehearsal_nccl = os.environ.get("CIMG_BENCH_REHEARSAL") == "nccl"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    red_dev = "cpu" if rehearsal else "cuda"
+    red_dev = "cpu" if rehearsal and not rehearsal_nccl else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        if rehearsal and not rehearsal_nccl:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if rehearsal_nccl:
+        rehearsal = False                                      # (from here on the run IS an nccl run; its numbers still mean nothing: one card)
 
     if args.config == 5:
         return run_config5(args, rank, world, local_rank, dist, red_dev)
@@ -931,7 +936,7 @@ def main():
             exchange = {"what": "finished chunks of every rank gathered to rank 0 (packed compressed bytes, exact sizes, "
                                 "batch_isend_irecv)", "bytes_moved": moved, "seconds": round(float(tmax.item()), 6),
                         "exchange_GBps": round(moved / float(tmax.item()) / 1e9, 3) if moved else None,
-                        "backend": "gloo (rehearsal on one GPU: meaningless as a number)" if rehearsal else "nccl (RCCL over xGMI)",
+                        "backend": "gloo (rehearsal on one GPU: meaningless as a number)" if rehearsal else ("nccl (RCCL), REHEARSAL with every rank on one GPU: meaningless as a number" if os.environ.get("CIMG_BENCH_REHEARSAL") == "nccl" else "nccl (RCCL over xGMI)"),
                         "complete": bool(ok)}
     if not torch.equal(d_out, d_raw) and not no_verify:
         print("bench.py: pixels differ after the timed region", file=sys.stderr)

@@ -1186,7 +1186,7 @@ static int decompress_finish(cimg_engine* e, int32_t* status)
         return 0;
     };
     rc = read_path();
-    if (rc) return rc;
+    if (rc) { if (ztimed) e->free_events.push_back(zev); return rc; }
     if (ztimed) { (void)hipEventRecord(zev.b, e->stream); e->pending[CIMG_K_DECODE_ZSTD].push_back(zev); }
     if (launched) {
         if ((rc = cimg_engine_synchronize(e))) return rc;
@@ -1306,11 +1306,18 @@ struct HostPin {
         for (const auto& r : runs) {
             if (nruns >= MAX_RUNS) break;
             if (r.second - r.first < (4ll << 20)) continue;
+            // The run is rounded OUTWARD to whole pages: a copy whose source is page-locked in the middle and pageable at its ends is
+            // refused by the runtime ("invalid argument" -- tried in round 5 after ADVICE r4 asked for inward rounding).  What the
+            // advice was after is kept where it can be: "page-locked already" needs BOTH ends of the run to say so, and a run that is
+            // locked at one end only -- partly inside somebody else's registration -- is left pageable rather than registered across it.
             const uintptr_t a = ((uintptr_t)host + (uintptr_t)r.first) & ~(uintptr_t)4095;
             const uintptr_t b = (((uintptr_t)host + (uintptr_t)r.second) + 4095) & ~(uintptr_t)4095;
-            hipPointerAttribute_t at{};
-            if (hipPointerGetAttributes(&at, (const void*)a) == hipSuccess && at.type != hipMemoryTypeUnregistered) continue;   // page-locked already
+            hipPointerAttribute_t at{}, at2{};
+            const bool first_locked = hipPointerGetAttributes(&at, (const void*)a) == hipSuccess && at.type != hipMemoryTypeUnregistered;
             (void)hipGetLastError();
+            const bool last_locked = hipPointerGetAttributes(&at2, (const void*)(b - 4096)) == hipSuccess && at2.type != hipMemoryTypeUnregistered;
+            (void)hipGetLastError();
+            if (first_locked || last_locked) continue;                  // page-locked already, or partly somebody else's registration
             if (hipHostRegister((void*)a, (size_t)(b - a), hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); continue; }
             base[nruns++] = (void*)a;
             e->host_registrations++;
