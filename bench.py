@@ -188,7 +188,9 @@ def kernel_source_hash():
 
 
 def pmc_traffic(kernel, explicit=None):
-    path = explicit or next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_per_launch.json") for r in ("r04", "r03")) if os.path.exists(q)), "")
+    # (the newest round's counters first: the file names the kernel sources it was collected on, and only a match is reported)
+    rounds = sorted((r for r in os.listdir(os.path.join(ROOT, "profiles")) if r[:1] == "r" and r[1:].isdigit()), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    path = explicit or next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_per_launch.json") for r in rounds) if os.path.exists(q)), "")
     if not os.path.exists(path):
         return None, None
     try:

@@ -1,5 +1,7 @@
+# profiles/tools/extra.sh <tag> -- run ON THE GPU BOX (via gpurun) from the repo root: everything in profiles/<tag>/ besides the four files of collect.sh
 set -x
-out=gpurun_out/prof/r04
+tag=${1:-r05}
+out=gpurun_out/prof/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 300 python bench.py --config 1 > $out/bench_config1.json 2> $out/bench_config1.err
@@ -25,3 +27,10 @@ echo "[extra] numbers done"
   echo "## tools/diag_real_sizes.py"; timeout -k 10 300 python tools/diag_real_sizes.py 2>&1 | tail -12;
   echo "## tools/diag_pymodule.py"; timeout -k 10 300 python tools/diag_pymodule.py 2>&1 | tail -12; } > $out/host_path.txt
 echo "[extra] host path done"
+{ echo "## tools/diag_dtypes.py lz4"; timeout -k 10 400 python tools/diag_dtypes.py lz4 2>&1 | grep -v amdgpu;
+  echo "## tools/diag_dtypes.py blosclz"; timeout -k 10 400 python tools/diag_dtypes.py blosclz 2>&1 | grep -v amdgpu;
+  echo "## CIMG_ENC_RT=1 tools/diag_dtypes.py lz4   (the register-table form of the encoder, experimental: encode_rt_kernel.h)"; CIMG_ENC_RT=1 timeout -k 10 400 python tools/diag_dtypes.py lz4 2>&1 | grep -v amdgpu; } > $out/dtypes.txt
+echo "[extra] dtypes done"
+timeout -k 5 60 tests/ubench/regtab > $out/ubench_regtab.txt 2>&1
+timeout -k 10 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/rehearse_nccl.py 2>&1 | grep "nccl rehearsal" > $out/nccl_rehearsal.txt
+echo "[extra] ubench + rccl rehearsal done"
