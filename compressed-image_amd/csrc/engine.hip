@@ -249,7 +249,7 @@ struct cimg_engine {
     int64_t zstd_blocks_refused = 0;    // blocks whose plan did not fit its slot (decoded by cimg_decode_zstd behind the two launches)
     int zstd_fused = getenv("CIMG_ZSTD_FUSED") ? atoi(getenv("CIMG_ZSTD_FUSED")) : 0;          // 1: cimg_decode_zstd only (no walk / replay launches)
     int zstd_plan_cap = getenv("CIMG_ZSTD_PLAN_CAP") ? atoi(getenv("CIMG_ZSTD_PLAN_CAP")) : 0;   // diagnostic: bytes of records / literals a plan may take (0: the block area)
-    int64_t zstd_plan_bytes = getenv("CIMG_ZSTD_PLAN_MIB") ? atoll(getenv("CIMG_ZSTD_PLAN_MIB")) << 20 : 512ll << 20;   // device memory for the plans of one group of launches (a plan is ~4.25 x its block: 139 KB for 32 KiB; larger batches go in groups; round 4 took up to 2 GiB and kept it: ADVICE r4)
+    int64_t zstd_plan_bytes = getenv("CIMG_ZSTD_PLAN_MIB") ? atoll(getenv("CIMG_ZSTD_PLAN_MIB")) << 20 : 1024ll << 20;   // device memory for the plans of one group of launches (a plan is ~4.25 x its block: 139 KB for 32 KiB; larger batches go in groups; round 4 took up to 2 GiB and kept it: ADVICE r4.  Measured on configs[4]'s share, 1 GiB of libzstd-22 chunks: 2 GiB = 2 groups 17.9 ms, 512 MiB = 9 groups 19.6 ms)
     bool zstd_plan_fail = getenv("CIMG_ZSTD_PLAN_FAIL") != nullptr;   // test hook: the plans' device memory cannot be had (the fused kernel reads the batch)
     int zstd_walk_stage = getenv("CIMG_ZSTD_WALK_STAGE") ? atoi(getenv("CIMG_ZSTD_WALK_STAGE")) : 2048;   // bytes of LDS through which a walker reads a frame's sections (measured on 128 MiB of level-22 float32: 8192 = 8 waves a CU 2.51 ms, 4096 = 10 waves 2.45, 2048 = 11 waves 2.28 -- a section that does not fit is read where it lies)
     int zstd_lanes = getenv("CIMG_ZSTD_LANES") ? atoi(getenv("CIMG_ZSTD_LANES")) : 8;   // blocks a wave of cimg_zstd_seq decodes side by side (0: the walkers decode sequences themselves)
