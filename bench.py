@@ -697,6 +697,9 @@ def run_config5(args, rank, world, local_rank, dist, red_dev):
                                "sample": f"libzstd {O.zstd_version()} under the oracle's chunk layer on the same channel: one compress pass at clevel {clevel} on {cores} threads "
                                          f"({t_make:.1f} s), {reps} decompress passes on {thr} threads ({td:.1f} s)"}
     if rank == 0:
+        # (how many blocks went through the fused fallback -- plans that did not fit their slots -- belongs in the record)
+        out["zstd_read_path_stats"] = eng.zstd_stats()
+    if rank == 0:
         print(json.dumps(out))
     eng.close()
     if dist is not None:
