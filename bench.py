@@ -38,6 +38,7 @@ CHANNELS = 4
 DTYPE = np.float16
 CHUNK = 4 * 1024 * 1024
 BLOCK = 32768
+EXCHANGE_TIMEOUT_S = int(os.environ.get("CIMG_BENCH_EXCHANGE_TIMEOUT", "120"))        # main(), N > 1: how long the gather of the finished chunks may take before the line is printed without it
 
 
 def _oracle_batch_lib():
@@ -908,41 +909,53 @@ def main():
     # ---- the exchange step of SURVEY.md section 8e (N > 1): every rank's finished chunks travel to rank 0, packed,
     # point to point with exact sizes (cimg/shard.py: gather_chunks; "nccl" = RCCL send/recv over xGMI).  Timed on its own,
     # after the codec region: it belongs to a caller that wants the whole result on one device, not to the codec path.
-    exchange = None
-    if dist is not None:
-        from cimg import shard
-        per_group = nchunks
-        if strong:
-            n_items = N_image // CHUNK
-            per_group = n_items // CHANNELS
-            mine = shard.partition(n_items, world, rank, items_per_group=per_group)
-        else:
-            n_items = world * nchunks
-            mine = shard.partition(n_items, world, rank, items_per_group=nchunks)    # rank r owns its own images: items r*nchunks ...
-        sizes_all = shard.gather_sizes(dist, mine, cbytes, n_items, device=red_dev)
-        comp_view = d_comp if not rehearsal else d_comp.cpu()
-        xdev = "cpu" if rehearsal else "cuda"
-        for rep in range(3):                                    # first pass warms the communicator
-            dist.barrier()
-            torch.cuda.synchronize()
-            tx = time.perf_counter()
-            got = shard.gather_chunks(dist, world, rank, mine, comp_view, comp_off, sizes_all, n_items, dst=0,
-                                      items_per_group=per_group, device=xdev, as_tensor=True)
-            torch.cuda.synchronize()
-            dist.barrier()
-            tx = time.perf_counter() - tx
-        tmax = torch.tensor([tx], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        moved = int(sizes_all.sum() - sizes_all[shard.partition(n_items, world, 0, per_group)].sum())
-        if rank == 0:
-            whole, offs, szs = got
-            probe = int(mine[0]) if len(mine) else 0
-            ok = whole.numel() == int(sizes_all.sum())
-            exchange = {"what": "finished chunks of every rank gathered to rank 0 (packed compressed bytes, exact sizes, "
-                                "batch_isend_irecv)", "bytes_moved": moved, "seconds": round(float(tmax.item()), 6),
-                        "exchange_GBps": round(moved / float(tmax.item()) / 1e9, 3) if moved else None,
-                        "backend": "gloo (rehearsal on one GPU: meaningless as a number)" if rehearsal else ("nccl (RCCL), REHEARSAL with every rank on one GPU: meaningless as a number" if os.environ.get("CIMG_BENCH_REHEARSAL") == "nccl" else "nccl (RCCL over xGMI)"),
-                        "complete": bool(ok)}
+    # It runs LAST, behind a watchdog (below): nothing it does -- a refusal, a hang of the communicator -- may cost the line its
+    # codec measurement.
+    def run_exchange():
+        exchange = None
+        # (test hook, tools/... rehearsals only: CIMG_BENCH_EXCHANGE_FAULT = "raise:<rank>" / "hang:<rank>" injects a failure of the exchange
+        # on one rank, to show that the line survives it)
+        fault = os.environ.get("CIMG_BENCH_EXCHANGE_FAULT", "")
+        if fault == f"raise:{rank}":
+            raise RuntimeError("injected exchange failure")
+        if fault == f"hang:{rank}":
+            time.sleep(10 ** 6)
+        if dist is not None:
+            from cimg import shard
+            per_group = nchunks
+            if strong:
+                n_items = N_image // CHUNK
+                per_group = n_items // CHANNELS
+                mine = shard.partition(n_items, world, rank, items_per_group=per_group)
+            else:
+                n_items = world * nchunks
+                mine = shard.partition(n_items, world, rank, items_per_group=nchunks)    # rank r owns its own images: items r*nchunks ...
+            sizes_all = shard.gather_sizes(dist, mine, cbytes, n_items, device=red_dev)
+            comp_view = d_comp if not rehearsal else d_comp.cpu()
+            xdev = "cpu" if rehearsal else "cuda"
+            for rep in range(3):                                    # first pass warms the communicator
+                dist.barrier()
+                torch.cuda.synchronize()
+                tx = time.perf_counter()
+                got = shard.gather_chunks(dist, world, rank, mine, comp_view, comp_off, sizes_all, n_items, dst=0,
+                                          items_per_group=per_group, device=xdev, as_tensor=True)
+                torch.cuda.synchronize()
+                dist.barrier()
+                tx = time.perf_counter() - tx
+            tmax = torch.tensor([tx], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            moved = int(sizes_all.sum() - sizes_all[shard.partition(n_items, world, 0, per_group)].sum())
+            if rank == 0:
+                whole, offs, szs = got
+                probe = int(mine[0]) if len(mine) else 0
+                ok = whole.numel() == int(sizes_all.sum())
+                exchange = {"what": "finished chunks of every rank gathered to rank 0 (packed compressed bytes, exact sizes, "
+                                    "batch_isend_irecv)", "bytes_moved": moved, "seconds": round(float(tmax.item()), 6),
+                            "exchange_GBps": round(moved / float(tmax.item()) / 1e9, 3) if moved else None,
+                            "backend": "gloo (rehearsal on one GPU: meaningless as a number)" if rehearsal else ("nccl (RCCL), REHEARSAL with every rank on one GPU: meaningless as a number" if os.environ.get("CIMG_BENCH_REHEARSAL") == "nccl" else "nccl (RCCL over xGMI)"),
+                            "complete": bool(ok)}
+        return exchange
+
     if not torch.equal(d_out, d_raw) and not no_verify:
         print("bench.py: pixels differ after the timed region", file=sys.stderr)
         sys.exit(3)
@@ -1071,7 +1084,7 @@ def main():
             "natural_family": natural,
             "dtypes": dtypes,
             "last_step_verified": "d_out cleared in front of the last timed step, pixels compared with the input after it",
-            "exchange": exchange,
+            "exchange": None,
             "kernel_timing": f"HIP events around every kernel of every {TIMING_PERIOD}th batch call inside the timed region",
             "step_calls": ("cimg_compress_batch_device + cimg_decompress_batch_device (one wait each)" if sync_calls else
                            "cimg_compress_batch_device_begin, cimg_decompress_batch_device_begin, then both _fetch (sizes and status on the host every step)"),
@@ -1097,7 +1110,33 @@ def main():
             real = cblosc2_baseline(host)                     # only where a c-blosc2 library is installed
             if real is not None:
                 out["cpu_baseline_cblosc2"] = real
-        print(json.dumps(out))
+    if dist is not None:
+        # the exchange, behind a watchdog: a rank whose exchange has not come back after EXCHANGE_TIMEOUT_S leaves -- rank 0 with the
+        # line it has (exchange: the reason), the others silently -- instead of sitting in a collective until the job is killed
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["exchange"] = {"error": f"the exchange step did not complete within {EXCHANGE_TIMEOUT_S} s (the codec figures above are unaffected)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        timer = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
+        timer.daemon = True
+        timer.start()
+        try:
+            ex = run_exchange()
+        except Exception as err:                                # noqa: BLE001 -- whatever the communicator says goes into the record
+            ex = {"error": f"{type(err).__name__}: {str(err).splitlines()[0][:300] if str(err) else ''}"}
+        timer.cancel()
+        if rank == 0:
+            out["exchange"] = ex
+        if isinstance(ex, dict) and "error" in ex:
+            # (the communicator is in an unknown state: no further collective -- the line, then out)
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.barrier()

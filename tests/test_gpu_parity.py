@@ -892,7 +892,7 @@ def test_zstd_chunks_made_on_this_box(eng, golden_dir):
     # with repeated tables / treeless literals and the repeat offsets carried over)
     # (... which only the planned path holds: under the switches that send blocks to cimg_decode_zstd -- tools/switch_matrix.sh -- that
     # size is the documented ERR_CODEC_SUPPORT, tests/test_emu_zstd.py has the case)
-    to_fused = os.environ.get("CIMG_ZSTD_FUSED") or os.environ.get("CIMG_ZSTD_PLAN_CAP")
+    to_fused = os.environ.get("CIMG_ZSTD_FUSED") or os.environ.get("CIMG_ZSTD_PLAN_CAP") or os.environ.get("CIMG_ZSTD_PLAN_FAIL")
     for bs in ((131072, 65536, 4096) if to_fused else (147456, 131072, 65536, 4096)):
         chunks = [G.frame(z, src, 2, bs, clevel) for clevel in (3, 9)]
         outs, status = eng.decompress_host(chunks)
