@@ -1466,7 +1466,7 @@ struct EncodeStream {
                 }
                 need = cb;                                    // a frame fits a budget iff the budget holds its bytes
             }
-            else if constexpr (CODEC == CODEC_LZ4_RT) cb = lz4_encode_rt_body(lds, neblock, out, neblock, accel_or_level, need);
+            else if constexpr (CODEC == CODEC_LZ4_RT) cb = lz4_encode_rt_body(lds, neblock, out, neblock, accel_or_level, need, dbg, item);
             else cb = lz4_encode_wave(lds, 0, round16(neblock), neblock, out, neblock, accel_or_level, &need, dbg, item);
             if (cb > 0 && cb < neblock) {
                 r.kind = REC_LZ4; r.csize = cb; r.need = need;

@@ -85,9 +85,11 @@ CIMG_DEV int rt_batch_size(int done)
 // registers, and every further place that modified it -- or a loop nest that carried it -- made the compiler keep second copies of
 // both tuples and move 64 registers at the joins.  A step = [lay a window out] -> enter a batch of probes into the table (or take the
 // probes behind a hit out again) -> compare candidates / extend -> sequence.
-CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, int cap, int accel, int& need_out)
+CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, int cap, int accel, int& need_out, uint64_t* dbg = nullptr, int item = 0)
 {
     cimg_global_u8p out = CIMG_AS_GLOBAL(out_generic);
+    CIMG_PROF_DECL;
+    (void)dbg; (void)item;
     CIMG_RT_DECL;
     const int mflimit_p1 = n - 11, matchlimit = n - 5;
     const int s64 = accel << 6;
@@ -135,6 +137,7 @@ CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, 
                 nv = popc64(ballot(valid));
                 FOR_LANES(l) { W[l] = lds_ld32u(in, valid[l] ? pos[l] : 0); H[l] = lz4_hash<13>(W[l]); }
                 j = 0;
+                CIMG_PROF_LAP(0); CIMG_PROF_COUNT(0);              // window laid out
             }
             int bs = 1;
             if (!undo) {
@@ -156,6 +159,7 @@ CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, 
                 const uint32_t o = rt_xchg(CIMG_RT_ARGS, readlane(H, t), v);
                 setlane(OLD, t, o);
             }
+            CIMG_PROF_LAP(1); CIMG_PROF_COUNT(1);                  // table phase
             int p, old;
             if (undo) {
                 undo = 0;
@@ -171,6 +175,7 @@ CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, 
                     hit[l] = mine & (lds_ld32u(in, mine ? (int)OLD[l] : 0) == W[l]);
                 }
                 const uint64_t hm = ballot(hit);
+                CIMG_PROF_LAP(2);                                       // candidates of a batch compared
                 if (!hm) { j = tb; continue; }
                 j = ctz64(hm);
                 p = readlane(pos, j);
@@ -198,6 +203,7 @@ CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, 
                 eq[l] = (l < room) & (pa == pb);
             }
             const uint64_t sm = ballot(stop);
+            CIMG_PROF_LAP(3); CIMG_PROF_COUNT(3);                  // candidate + extension round trip
             if (sm & 1) { j += 1; continue; }                           // the four bytes differ: no match at this probe
             int mcode;
             if (sm) { const int f = ctz64(sm); mcode = 4 * (f - 1) + readlane(len, f); }
@@ -225,6 +231,7 @@ CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, 
                 np = 0;
             }
             const int ipe = ip + mcode + 4;
+            CIMG_PROF_LAP(4); CIMG_PROF_COUNT(2);                  // sequence parked
             anchor = ipe;
             if (ipe >= mflimit_p1) break;
             s = ipe + 1;
@@ -248,6 +255,8 @@ CIMG_DEV int lz4_encode_rt_body(const uint8_t* in, int n, uint8_t* out_generic, 
         emit_literals(in, anchor, out, op, run);
         op += run;
     }
+    CIMG_PROF_LAP(6);
+    CIMG_PROF_STORE(dbg, item);
     need_out = need;
     return op;
 }
