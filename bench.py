@@ -994,7 +994,9 @@ def main():
         dtypes = {}
         for dt_name, fam in (("uint8", "natural"), ("float32", "tiled")):
             dt = np.dtype(dt_name)
-            pix = np.ascontiguousarray(getattr(synth, fam + "_channel")(dt.type, WIDTH, N // (WIDTH * dt.itemsize))).view(np.uint8).ravel()
+            # (as channels of 4096 x 4096, like the headline's: one tall image would cost the generator gigabytes of float64 temporaries)
+            per = WIDTH * HEIGHT * dt.itemsize
+            pix = np.concatenate([np.ascontiguousarray(getattr(synth, fam + "_channel")(dt.type, WIDTH, HEIGHT, c=k)).view(np.uint8).ravel() for k in range(N // per)])
             d_raw.copy_(torch.from_numpy(pix).cuda())
             pd = hip.cparams(dt.itemsize, clevel=9, blocksize=BLOCK, compcode=hip.LZ4, filters=(0, 0, 0, 0, 0, hip.SHUFFLE))
             def dstep():
