@@ -118,3 +118,39 @@ def test_two_gloo_ranks_reproduce_single_process_sizes():
         assert t == 2.0                                                                 # max over ranks
         if rank == 0:
             assert digest == want_digest                                                # gathered chunks == single-process chunks
+
+
+def test_four_gloo_ranks_more_ranks_than_channels():
+    """World size 4 over 3 channels of 4 chunks: fewer channels than ranks, so the partition goes chunk-granular (SURVEY.md section 8e:
+    configs[1] at 8 GPUs is this shape) -- every rank compresses its chunks, the sizes, the gather to rank 0 and the scatter back are
+    exact, and the gathered chunks are the single-process ones."""
+    import torch.multiprocessing as mp
+    import _oracle as O
+    O.lib()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 4
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owned = [m for _, m, _, _, _ in res]
+    assert sorted(i for m in owned for i in m) == list(range(12))                      # every chunk exactly once
+    assert owned == [shard.partition(12, world, r, 4).tolist() for r in range(world)]
+    assert owned[0] == [0, 4, 8]                                                         # 3 channels < 4 ranks: chunk-granular round-robin
+    chans = [synth.tiled_channel(np.uint16, 512, 256, c=c) for c in range(3)]
+    raw = np.concatenate([c.view(np.uint8).ravel() for c in chans])
+    blobs = [O.compress(O.cparams(2), raw[i * 65536:(i + 1) * 65536], destsize=65536 + 32) for i in range(12)]
+    want_digest = [int(np.frombuffer(c[:r], dtype=np.uint8).astype(np.uint64).sum()) * 1000003 + r for r, c in blobs]
+    for rank, mine, full, t, digest in res:
+        assert full == [r for r, _ in blobs]
+        assert t == float(world)                                                        # max over ranks of 1 + rank
+        if rank == 0:
+            assert digest == want_digest
