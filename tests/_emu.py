@@ -78,6 +78,12 @@ def set_write_order(o):
     lib().emu_set_write_order(o)
 
 
+def set_zstd_lose_fused(on):
+    """Test hook: the fused kernel does not run behind the replay (blocks the walk refused stay undecoded)."""
+    lib().emu_set_zstd_lose_fused.argtypes = [C.c_int]
+    lib().emu_set_zstd_lose_fused(int(on))
+
+
 def set_zstd_plan(cap):
     """The zstd read path of the emulated batch decode: -1 = walk + replay launches with plans of the block area (the engine's
     default), 0 = the fused kernels only, n = plans of n bytes (small: plans overflow and their blocks go to the fused kernels)."""

@@ -134,6 +134,8 @@ int g_emu_lean = 1;            // tests switch the lean kernel off to cover the 
 long g_emu_lean_blocks = 0;    // blocks the lean kernel produced since the last emu_stats reset
 extern "C" void emu_set_lean(int on) { g_emu_lean = on; }
 extern "C" void emu_set_zstd_plan(int cap) { g_emu_zstd_plan_cap = cap; }
+static int g_emu_zstd_lose_fused = 0;   // test hook: the fused pass behind the replay does not happen (what a lost refusal count did before round 5)
+extern "C" void emu_set_zstd_lose_fused(int on) { g_emu_zstd_lose_fused = on; }
 extern "C" void emu_set_zstd_lanes(int n) { g_emu_zstd_lanes = n; }
 extern "C" long emu_zstd_refused() { const long r = g_emu_zstd_refused; g_emu_zstd_refused = 0; return r; }
 extern "C" long emu_lean_blocks(void) { const long n = g_emu_lean_blocks; g_emu_lean_blocks = 0; return n; }
@@ -250,7 +252,7 @@ int emu_decompress_batch(int nchunks, const uint8_t* comp, const int64_t* comp_o
     int pending = 0;
     for (int b = 0; b < plan.total_blocks; b++) pending += fallwords[(size_t)b + 1] == ZFALL_PENDING;
     if (planned && pending != (no_fused ? 0 : (int)refused)) return -1;           // (every refused plan is a pending block, and nothing else is)
-    const bool run_fused = (unread[0] || unread[1]) && (!planned || (pending > 0 && !no_fused));
+    const bool run_fused = (unread[0] || unread[1]) && (!planned || (pending > 0 && !no_fused)) && !(planned && g_emu_zstd_lose_fused);
     if (!run_fused) { unread[0] = false; unread[1] = false; }
     const bool two_waves = unread[1] && zstd_kernel_lds_bytes(max_bs, 2) <= 163840;       // (engine.hip: decompress_finish)
     if (!two_waves) { unread[0] = unread[0] || unread[1]; unread[1] = false; }

@@ -92,6 +92,25 @@ def test_plans_that_do_not_fit_are_counted_and_their_blocks_still_decode(kat, zs
     assert (refused > 0) == (zstd_read_path == "plans_overflow"), (zstd_read_path, refused)
 
 
+def test_a_block_nobody_decoded_fails_the_batch(kat, zstd_read_path):
+    """a block whose plan the walk refused used to hang on ONE counter -- had that count been lost, the fused kernel would
+    not have run and the call would have reported success over pixels that were never written.  Every such block now carries its own
+    pending word until cimg_decode_zstd has taken it: with the fused pass suppressed, the batch FAILS."""
+    if zstd_read_path != "plans_overflow":
+        pytest.skip("only plans that do not fit leave blocks to the fused kernel")
+    name = "natural_f32_split"
+    chunk = kat["chunk|" + name]; src = kat["cin|" + name]
+    bs = int(np.frombuffer(chunk[8:12].tobytes(), "<i4")[0])
+    E.set_zstd_lose_fused(1)
+    try:
+        rc, status, out = E.decompress_batch([chunk.tobytes()], [src.size], [bs])
+        assert rc != 0, "blocks left pending went unnoticed"
+    finally:
+        E.set_zstd_lose_fused(0)
+    rc, status, out = E.decompress_batch([chunk.tobytes()], [src.size], [bs])
+    assert rc == 0 and out[0].tobytes() == src.tobytes()
+
+
 def test_split_and_unsplit_zstd_chunks_in_one_batch(kat):
     """Split chunks go to the two-waves-per-block launch, chunks of one stream per block to the one-wave launch (engine.hip:
     decompress_finish; each launch reads its own kind only): one batch with both, and LZ4 chunks between them."""
